@@ -1,0 +1,132 @@
+"""Generate golden vectors from the REFERENCE's own classes (run once, in the build
+container, where /root/reference is mounted). Output: small .npz files next to
+this script, committed. Nothing here runs on the GPU box.
+
+The reference module /root/reference/foundation_model/src/model.py imports two
+third-party packages that are absent offline (timm, segmentation_models_pytorch);
+they are only needed by FoundationModel.__init__, not by the head classes, so
+they are replaced by empty module objects for the import.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from seeding import load_seeded, randn  # noqa: E402
+
+REF = "/root/reference/foundation_model"
+
+
+def import_reference_model():
+    sys.dont_write_bytecode = True
+    for name in ("timm", "segmentation_models_pytorch"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.path.insert(0, REF)
+    from src import model as ref  # type: ignore
+    sys.path.pop(0)
+    return ref
+
+
+def grad_digest(t: torch.Tensor) -> np.ndarray:
+    """[sum, l2, first 16 values] — enough to pin a large gradient without storing it."""
+    f = t.detach().double().flatten()
+    head = f[:16].numpy()
+    if head.size < 16:
+        head = np.pad(head, (0, 16 - head.size))
+    return np.concatenate([[f.sum().item(), f.norm().item()], head]).astype(np.float64)
+
+
+def run_module(mod, x, train: bool, full_grads: bool):
+    mod.train(train)
+    x = x.clone().requires_grad_(True)
+    out = mod(x)
+    res = {"out": out.detach().numpy()}
+    if train:
+        # fixed, non-trivial upstream gradient
+        g = randn(777, *out.shape)
+        out.backward(g)
+        res["dx"] = x.grad.numpy()
+        for k, p in mod.named_parameters():
+            if p.grad is None:
+                continue
+            res["grad." + k] = p.grad.numpy() if full_grads else grad_digest(p.grad)
+        for k, b in mod.named_buffers():
+            if "running" in k:
+                res["buf." + k] = b.detach().numpy().copy()
+    return res
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    ref = import_reference_model()
+
+    # G1: CBAM (model.py:96-108)
+    for (c, hw, tag, full) in ((384, 10, "c384_10x10", False), (64, 2, "c64_2x2", True), (64, 5, "c64_5x5", True)):
+        for train in (True, False):
+            m = load_seeded(ref.CBAM(c), 11)
+            x = randn(12, 2, c, hw, hw)
+            r = run_module(m, x, train, full)
+            np.savez_compressed(os.path.join(HERE, f"cbam_{tag}_{'train' if train else 'eval'}.npz"), **r)
+
+    # G2: MultiHeadAttentionClassifier (model.py:112-175), dropout 0 so train mode is deterministic
+    for (c, hw, ncls, tag, full) in ((384, 10, 4, "c384_10x10", False), (384, 2, 4, "c384_2x2", False), (64, 3, 2, "c64_3x3", True)):
+        for train in (True, False):
+            m = load_seeded(ref.MultiHeadAttentionClassifier(c, 8, ncls, dropout=0.0), 21)
+            x = randn(22, 2, c, hw, hw)
+            r = run_module(m, x, train, full)
+            np.savez_compressed(os.path.join(HERE, f"mha_{tag}_{'train' if train else 'eval'}.npz"), **r)
+
+    # G3: simple head (model.py:308-316) — built exactly as the reference builds it
+    import torch.nn as nn
+    for (c, hw, ncls, tag) in ((384, 10, 4, "c384_10x10"),):
+        head = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Dropout(0.0), nn.Linear(c, 512),
+                             nn.ReLU(), nn.Dropout(0.0), nn.Linear(512, ncls))
+        m = load_seeded(head, 31)
+        x = randn(32, 2, c, hw, hw)
+        r = run_module(m, x, True, True)
+        np.savez_compressed(os.path.join(HERE, f"simple_{tag}_train.npz"), **r)
+
+    # G4: ChannelPool channel order [max, mean] (model.py:77-79)
+    x = randn(41, 2, 16, 3, 3)
+    np.savez_compressed(os.path.join(HERE, "channelpool.npz"), out=ref.ChannelPool()(x).numpy())
+
+    # G5: load_model_weights_safely key handling (model.py:549-604) on a toy module
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Linear(2, 2)
+            self.b = nn.Linear(2, 2)
+    toy = Toy()
+    sd = {"a.weight": torch.ones(2, 2), "a.bias": torch.zeros(2), "classifier.weight": torch.ones(1),
+          "bn2.running_mean": torch.ones(1), "conv_head.weight": torch.ones(1), "zzz.weight": torch.ones(1)}
+    missing, unexpected = ref.load_model_weights_safely(toy, {"model_state_dict": sd}, suppress_warnings=True)
+    missing2, unexpected2 = ref.load_model_weights_safely(Toy(), sd, suppress_warnings=True)
+    assert (missing, unexpected) == (missing2, unexpected2)
+    with open(os.path.join(HERE, "load_weights_keys.txt"), "w") as f:
+        f.write("missing=" + ",".join(missing) + "\n")
+        f.write("unexpected=" + ",".join(unexpected) + "\n")
+
+    # G6: parameter counts of the reference-owned modules
+    counts = {
+        "CBAM(384)": sum(p.numel() for p in ref.CBAM(384).parameters()),
+        "MHA(384,8,4)": sum(p.numel() for p in ref.MultiHeadAttentionClassifier(384, 8, 4).parameters()),
+        "MHA(384,8,2)": sum(p.numel() for p in ref.MultiHeadAttentionClassifier(384, 8, 2).parameters()),
+        "EnhancedUNetDecoder(nc=2)": sum(
+            p.numel() for p in ref.EnhancedUNetDecoder([24, 32, 48, 136, 384], num_classes=2).parameters()),
+    }
+    with open(os.path.join(HERE, "param_counts.txt"), "w") as f:
+        for k, v in counts.items():
+            f.write(f"{k}={v}\n")
+    print(counts)
+    print("state-dict keys of MHA head:", list(ref.MultiHeadAttentionClassifier(384, 8, 4).state_dict().keys()))
+
+
+if __name__ == "__main__":
+    main()
