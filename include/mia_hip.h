@@ -1,0 +1,121 @@
+/* libmia_hip.so -- C ABI of the MI355X (gfx950) kernels behind the EfficientNet-B3 + CBAM hot path.
+ *
+ * The reference (MMHS-09/medical-image-analysis) has no FFI seam of its own: its hot path is
+ * Python calling stock ATen/timm/OpenCV ops. Each entry point below therefore names the reference
+ * call site whose arithmetic it replaces (paths relative to the reference's foundation_model/).
+ *
+ * Conventions
+ *   - plain pointers to DEVICE memory, sizes as ints; no framework types. `stream` is a hipStream_t
+ *     passed as void* (0 = default stream). Nothing here allocates or synchronises.
+ *   - activations are NHWC, i.e. row-major [rows = B*H*W, C]; dtype: MIA_F32 or MIA_BF16 storage,
+ *     fp32 accumulation. Parameters, statistics and weight gradients are fp32.
+ *   - return 0 on success, negative on error; mia_last_error() gives the message (thread-local).
+ *   - train-mode BatchNorm: producers write per-workgroup partial sums into a caller-provided
+ *     fp32 slab part[part_rows][2][C] (every row is written; the caller picks 0 < part_rows <= 65535),
+ *     mia_bn_finalize_* reduces it. Consumers apply the resulting per-channel affine while loading.
+ */
+#ifndef MIA_HIP_H
+#define MIA_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MIA_F32 = 0, MIA_BF16 = 1 };
+enum { MIA_ACT_NONE = 0, MIA_ACT_SILU = 1, MIA_ACT_RELU = 2 };
+
+const char* mia_last_error(void);
+int mia_version(void);
+/* 0 iff the current HIP device is gfx950. */
+int mia_check_device(void);
+
+/* ---- pointwise (1x1) convolutions and linear layers: timm conv_pw / conv_pwl (src/model.py:283-288, :350),
+ *      nn.Linear in the heads (src/model.py:125-130, :138, :141, :312, :315) --------------------------------
+ * C[M,N] = pro(A)[M,K] . B[N,K]^T (+bias[N]) (epi_act) (+D[M,N], leading dim ldc)
+ * pro(a)[m,k] = pro_act(a*pscale[k] + pshift[k]) * gate[(m / rows_per_img)*K + k]   (each part optional)
+ * stats (optional): part[part_rows][2][N] <- column sums and sums of squares of the raw accumulators. */
+int mia_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* D, int M,
+                int N, int K, const float* pscale, const float* pshift, int pro_act, const float* gate,
+                int rows_per_img, const float* bias, int epi_act, float* stats, int part_rows, void* stream);
+
+/* Weight gradient (autograd of the ops above, train.py:370): O[N,K] (fp32, leading dim ldo) += G[M,N]^T . pro(X)[M,K].
+ * O must be zero-filled (or hold a gradient to accumulate into). */
+int mia_gemm_tn(int dtype, const void* G, int ldg, const void* X, int ldx, float* O, int ldo, int M, int N, int K,
+                const float* pscale, const float* pshift, int pro_act, const float* gate, int rows_per_img,
+                void* stream);
+
+/* ---- depthwise k x k convolutions: timm conv_dw (k in {3,5}, stride in {1,2}, pad (k-1)/2, no bias) ----------
+ * y[B,OH,OW,C] = dw(pro(x)[B,H,W,C]); pro = SiLU(x*pscale+pshift) when pscale != NULL; w is [C][k*k] fp32. */
+int mia_dwconv_fwd(int dtype, const void* x, int B, int H, int W, int C, const float* pscale, const float* pshift,
+                   const float* w, int K, int S, void* y, float* stats, int part_rows, void* stream);
+/* dx[B,H,W,C] from dy[B,OH,OW,C]. With yfwd != NULL the epilogue turns it into the gradient w.r.t. the
+ * pre-BatchNorm tensor's normalised activation: dx <- dx * silu'(yfwd*escale+eshift), and stats receives
+ * partials of sum(dx) and sum(dx * (yfwd-emean)*erstd). */
+int mia_dwconv_bwd_data(int dtype, const void* dy, int B, int H, int W, int C, const float* w, int K, int S, void* dx,
+                        const void* yfwd, const float* escale, const float* eshift, const float* emean,
+                        const float* erstd, float* stats, int part_rows, void* stream);
+/* dw[C][k*k] (fp32) += sum dy * pro(x); dw must be zero-filled first. */
+int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int W, int C, const float* pscale,
+                          const float* pshift, const void* dy, int K, int S, float* dw, void* stream);
+
+/* ---- BatchNorm: timm BatchNormAct2d (eps 1e-5, momentum 0.1) and CBAM's nn.BatchNorm2d(1, momentum 0.01)
+ *      (src/model.py:16) ------------------------------------------------------------------------------------
+ * training: batch statistics from part (count = rows reduced), running stats updated in place (unbiased
+ * variance), *num_batches_tracked += 1. eval: statistics = running stats. Outputs: scale = gamma*rstd,
+ * shift = beta - mean*scale, mean, rstd. */
+int mia_bn_finalize_fwd(const float* part, int P, int C, double count, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                        float eps, int training, float* scale, float* shift, float* mean, float* rstd, void* stream);
+/* part holds partials of (sum g, sum g*xhat). Outputs dgamma, dbeta (nullable) and the coefficients of
+ * dy = ca*g + cb*y + cd (y = raw pre-BN tensor). */
+int mia_bn_finalize_bwd(const float* part, int P, int C, double count, const float* gamma, const float* mean,
+                        const float* rstd, int training, float* dgamma, float* dbeta, float* ca, float* cb, float* cd,
+                        void* stream);
+/* g = (G*gate[b] + dpool[b]) * act'(Y*scale+shift) written over G (b = row / rows_per_img; gate, dpool optional);
+ * part <- partials of sum(g), sum(g*(Y-mean)*rstd). */
+int mia_bn_act_bwd_reduce(int dtype, void* G, const void* Y, long long R, int C, const float* scale,
+                          const float* shift, const float* mean, const float* rstd, int act, const float* gate,
+                          const float* dpool, int rows_per_img, float* part, int part_rows, void* stream);
+/* Out = act(a[c]*X + b[c]*Y + d[c]) + Res   (Y/b and Res optional; Out may alias X). */
+int mia_affine2(int dtype, const void* X, const void* Y, const void* Res, void* Out, long long R, int C,
+                const float* a, const float* b, const float* d, int act, void* stream);
+
+/* ---- squeeze-excite: timm SqueezeExcite (mean over H,W -> conv_reduce+bias -> SiLU -> conv_expand+bias -> sigmoid)
+ * out[b][split][c] = sum over the split's rows of Wt[r,c] * act(Y*scale+shift)   (Wt optional) */
+int mia_img_colsum(int dtype, const void* Y, const void* Wt, int B, int HW, int C, const float* scale,
+                   const float* shift, int act, int splits, float* out, void* stream);
+int mia_se_gate_fwd(const float* pool_part, int B, int splits, int HW, int C, int RD, const float* Wr,
+                    const float* br, const float* We, const float* be, float* pooled, float* hpre, float* gate,
+                    void* stream);
+int mia_se_gate_bwd(const float* dgate_part, int B, int splits, int HW, int C, int RD, const float* Wr,
+                    const float* We, const float* gate, const float* hpre, const float* pooled, float* dpre2,
+                    float* dpre1, float* dpool, float* dWr, float* dbr, float* dWe, float* dbe, void* stream);
+
+/* ---- stem: timm conv_stem (3->40, k3 s2 p1) as im2col + mia_gemm_nt. x is NCHW fp32 (the tensor the
+ *      reference feeds the model, train.py:345-351); col is [B*OH*OW][32], columns 27..31 zero. */
+int mia_stem_im2col(int dtype, const float* x, int B, int H, int W, void* col, void* stream);
+
+/* fp32 master weight [R][Cc] -> compute-dtype copy [R][ldd] and/or transpose [Cc][ldt], zero padded. */
+int mia_cast_pad_transpose(int dtype, const float* src, int R, int Cc, void* dst, int ldd, void* dstT, int ldt,
+                           void* stream);
+
+/* ---- preprocessing: A.Resize + A.Normalize + ToTensorV2 (src/dataset.py:247-251, inference.py:116-140) and the
+ *      no-transform fallback cv2.resize + /255 (src/dataset.py:180-182). src u8 [N,h,w,ch] (ch 1 or 3) ->
+ *      dst f32 [N,3,oh,ow]. mode 0: (x - 255*mean)*(1/(255*std)); mode 1: x/255. */
+int mia_resize_normalize_u8(const uint8_t* src, int N, int h, int w, int ch, float* dst, int oh, int ow,
+                            const float* mean3, const float* std3, int mode, void* stream);
+
+/* ---- zero-intensity slice filter. No counterpart in the reference (zi_remover.py:3-19 deletes Zone.Identifier
+ *      files); specification: keep[z] = any(vol[z] != 0), idx = ascending kept indices, count[0] = their number.
+ *      flags_ws: int32[n_slices] scratch. elem_bytes in {1,2,4}; is_float selects IEEE compare for 4-byte data. */
+int mia_zero_slice_filter(const void* vol, int elem_bytes, int is_float, long long n_slices, long long slice_elems,
+                          int* flags_ws, uint8_t* keep, int* idx, int* count, void* stream);
+/* out[k] = vol[idx[k]] for k < count[0] (count stays on the device: no host round trip). */
+int mia_gather_slices(const void* vol, int elem_bytes, long long n_slices, long long slice_elems, const int* idx,
+                      const int* count, void* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIA_HIP_H */

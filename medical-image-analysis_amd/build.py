@@ -1,0 +1,56 @@
+"""Builds libmia_hip.so (hand-written gfx950 kernels + C ABI) in-tree with hipcc.
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the .so travels to
+the GPU box with the source tree.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmia_hip.so")
+SOURCES = ["runtime.hip", "gemm.hip", "dwconv.hip", "pointwise.hip", "head.hip", "preprocess.hip"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for src in SOURCES:
+        path = os.path.join(CSRC, src)
+        if not os.path.exists(path):
+            continue
+        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        objs.append(obj)
+        if (not force) and os.path.exists(obj) and os.path.getmtime(obj) > max(
+                os.path.getmtime(path), os.path.getmtime(os.path.join(CSRC, "common.h"))):
+            continue
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,125 @@
+// Shared device/host helpers for the gfx950 kernels of libmia_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#define MIA_WAVE 64
+
+// ----------------------------------------------------------------------------------------------
+// error handling: every extern "C" entry returns 0 or a negative code and records a message.
+// ----------------------------------------------------------------------------------------------
+void mia_set_error(const char* fmt, ...);
+
+#define MIA_CHECK_ARG(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            mia_set_error(__VA_ARGS__);          \
+            return -1;                           \
+        }                                        \
+    } while (0)
+
+#define MIA_CHECK_LAUNCH(name)                                                     \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) {                                                    \
+            mia_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+            return -2;                                                             \
+        }                                                                          \
+    } while (0)
+
+// ----------------------------------------------------------------------------------------------
+// bf16 storage type (raw 16 bits) and conversions. Round-to-nearest-even through the compiler's
+// __bf16 cast (v_cvt_pk_bf16_f32 on gfx950), which keeps NaN a NaN.
+// ----------------------------------------------------------------------------------------------
+struct bf16_t {
+    uint16_t v;
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T x);
+template <>
+__device__ __forceinline__ float to_f32<float>(float x) { return x; }
+template <>
+__device__ __forceinline__ float to_f32<bf16_t>(bf16_t x) { return bf16_bits_to_f32(x.v); }
+
+template <typename T>
+__device__ __forceinline__ T from_f32(float x);
+template <>
+__device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) {
+    bf16_t r;
+    r.v = f32_to_bf16_bits(x);
+    return r;
+}
+
+// 4 consecutive channel values as fp32, loaded/stored with one vector access
+// (16 B for float, 8 B for bf16). Pointers must be aligned to that width.
+struct f4 {
+    float x, y, z, w;
+};
+
+template <typename T>
+__device__ __forceinline__ f4 load4(const T* p);
+template <>
+__device__ __forceinline__ f4 load4<float>(const float* p) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    return {v.x, v.y, v.z, v.w};
+}
+template <>
+__device__ __forceinline__ f4 load4<bf16_t>(const bf16_t* p) {
+    uint2 v = *reinterpret_cast<const uint2*>(p);
+    return {__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+            __uint_as_float(v.y & 0xffff0000u)};
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, f4 v);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, f4 v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v.x, v.y, v.z, v.w);
+}
+template <>
+__device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f4 v) {
+    uint2 o;
+    o.x = (uint32_t)f32_to_bf16_bits(v.x) | ((uint32_t)f32_to_bf16_bits(v.y) << 16);
+    o.y = (uint32_t)f32_to_bf16_bits(v.z) | ((uint32_t)f32_to_bf16_bits(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = o;
+}
+
+// ----------------------------------------------------------------------------------------------
+// activations
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
+// d/dx silu(x) = s(x) * (1 + x * (1 - s(x)))
+__device__ __forceinline__ float silu_gradf_(float x) {
+    float s = sigmoidf_(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+
+// ----------------------------------------------------------------------------------------------
+// wave (64-lane) reductions via DPP-lowered shuffles
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+enum { MIA_F32 = 0, MIA_BF16 = 1 };
+enum { MIA_ACT_NONE = 0, MIA_ACT_SILU = 1, MIA_ACT_RELU = 2 };

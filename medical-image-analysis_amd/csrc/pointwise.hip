@@ -1,0 +1,542 @@
+// Bandwidth-bound BatchNorm / squeeze-excite / elementwise kernels on NHWC [rows, C] matrices (gfx950).
+//
+// Train-mode BatchNorm is split in two: the producing conv/GEMM kernel emits per-workgroup partial
+// sums (rows of a [P][2][C] fp32 slab, fixed summation order => bit-reproducible), a one-wave-per-
+// channel finalize kernel turns them into the per-channel affine (scale, shift) that the CONSUMER
+// applies while loading, so a normalised tensor is never written to HBM. The backward mirrors it:
+// reduce kernels emit partials of sum(g) and sum(g*xhat), finalize emits the three coefficients of
+// dy = ca*g + cb*y + cd.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// thread -> (row-thread, 4-channel vector) mapping shared by the row-streaming kernels
+// ------------------------------------------------------------------------------------------------
+struct RowMap {
+    int CB, nvec, npt, c0, cbv, cv, pt, c;
+    bool valid;
+};
+// channel blocking: up to 1024 channels (256 vectors) per workgroup column
+static inline void host_colblock(int C, int* ncb, int* CB) {
+    *ncb = cdiv(C, 1024);
+    *CB = cdiv(cdiv(C, 4), *ncb) * 4;
+}
+__device__ __forceinline__ RowMap make_rowmap(int C, int CB, int block_col, int tid) {
+    RowMap m;
+    m.CB = CB;
+    m.nvec = CB / 4;
+    m.npt = 256 / m.nvec;
+    m.c0 = block_col * CB;
+    m.cbv = (C - m.c0) < CB ? (C - m.c0) : CB;
+    m.cv = tid % m.nvec;
+    m.pt = tid / m.nvec;
+    m.c = m.c0 + m.cv * 4;
+    m.valid = (m.cv * 4 < m.cbv) && (m.pt < m.npt);
+    return m;
+}
+// sum the per-thread f4 pairs over row-threads and write channel sums to outA[c0 + ch] (and outB)
+__device__ __forceinline__ void block_colsum2(float* red, const RowMap& m, int tid, f4 s, f4 q, float* outA,
+                                              float* outB) {
+    __syncthreads();
+    red[tid * 8 + 0] = s.x; red[tid * 8 + 1] = s.y; red[tid * 8 + 2] = s.z; red[tid * 8 + 3] = s.w;
+    red[tid * 8 + 4] = q.x; red[tid * 8 + 5] = q.y; red[tid * 8 + 6] = q.z; red[tid * 8 + 7] = q.w;
+    __syncthreads();
+    for (int ch = tid; ch < m.cbv; ch += 256) {
+        const int cv = ch >> 2, e = ch & 3;
+        float a = 0.f, b = 0.f;
+        for (int pt = 0; pt < m.npt; ++pt) {
+            a += red[(pt * m.nvec + cv) * 8 + e];
+            b += red[(pt * m.nvec + cv) * 8 + 4 + e];
+        }
+        outA[m.c0 + ch] = a;
+        if (outB) outB[m.c0 + ch] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm finalize (forward): partials -> scale/shift/mean/rstd, running-stat update
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* part, int P, int C, double count,
+                                                              const float* gamma, const float* beta, float* rmean,
+                                                              float* rvar, long long* nbt, float momentum, float eps,
+                                                              int training, float* scale, float* shift, float* mean,
+                                                              float* rstd) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= C) return;
+    float mu, var;
+    if (training) {
+        double s = 0.0, q = 0.0;
+        for (int r = lane; r < P; r += 64) {
+            s += (double)part[((size_t)r * 2 + 0) * C + c];
+            q += (double)part[((size_t)r * 2 + 1) * C + c];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            q += __shfl_xor(q, o, 64);
+        }
+        const double m = s / count;
+        double v = q / count - m * m;
+        if (v < 0.0) v = 0.0;
+        mu = (float)m;
+        var = (float)v;
+        if (lane == 0 && rmean) {
+            const double unb = count > 1.0 ? v * count / (count - 1.0) : v;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+            if (c == 0 && nbt) *nbt += 1;
+        }
+    } else {
+        mu = rmean[c];
+        var = rvar[c];
+    }
+    if (lane == 0) {
+        const float rs = 1.0f / sqrtf(var + eps);
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        scale[c] = g * rs;
+        shift[c] = b - mu * g * rs;
+        mean[c] = mu;
+        rstd[c] = rs;
+    }
+}
+
+extern "C" int mia_bn_finalize_fwd(const float* part, int P, int C, double count, const float* gamma,
+                                   const float* beta, float* running_mean, float* running_var,
+                                   long long* num_batches_tracked, float momentum, float eps, int training,
+                                   float* scale, float* shift, float* mean, float* rstd, void* stream) {
+    MIA_CHECK_ARG(C > 0 && scale && shift && mean && rstd, "mia_bn_finalize_fwd: bad arguments");
+    MIA_CHECK_ARG(!training || (part && P > 0 && count > 0), "mia_bn_finalize_fwd: training needs partials");
+    MIA_CHECK_ARG(training || (running_mean && running_var), "mia_bn_finalize_fwd: eval needs running stats");
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       part, P, C, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                       training, scale, shift, mean, rstd);
+    MIA_CHECK_LAUNCH("mia_bn_finalize_fwd");
+    return 0;
+}
+
+// backward finalize: partials of (sum g, sum g*xhat) -> dgamma, dbeta and dy = ca*g + cb*y + cd
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* part, int P, int C, double count,
+                                                              const float* gamma, const float* mean, const float* rstd,
+                                                              int training, float* dgamma, float* dbeta, float* ca,
+                                                              float* cb, float* cd) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int r = lane; r < P; r += 64) {
+        s += (double)part[((size_t)r * 2 + 0) * C + c];
+        q += (double)part[((size_t)r * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
+    if (lane == 0) {
+        const double g = gamma ? (double)gamma[c] : 1.0;
+        const double rs = rstd[c], mu = mean[c];
+        if (dgamma) dgamma[c] = (float)q;
+        if (dbeta) dbeta[c] = (float)s;
+        if (training) {
+            ca[c] = (float)(g * rs);
+            cb[c] = (float)(-g * rs * rs * q / count);
+            cd[c] = (float)(g * rs * (-s / count + mu * rs * q / count));
+        } else {
+            ca[c] = (float)(g * rs);
+            cb[c] = 0.f;
+            cd[c] = 0.f;
+        }
+    }
+}
+
+extern "C" int mia_bn_finalize_bwd(const float* part, int P, int C, double count, const float* gamma,
+                                   const float* mean, const float* rstd, int training, float* dgamma, float* dbeta,
+                                   float* ca, float* cb, float* cd, void* stream) {
+    MIA_CHECK_ARG(part && P > 0 && C > 0 && count > 0 && mean && rstd && ca && cb && cd,
+                  "mia_bn_finalize_bwd: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       part, P, C, count, gamma, mean, rstd, training, dgamma, dbeta, ca, cb, cd);
+    MIA_CHECK_LAUNCH("mia_bn_finalize_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward reduce: g = (G * gate[b] + dpool[b]) * act'(y*scale+shift), written over G;
+// partials sum(g), sum(g * (y-mean)*rstd) per channel
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(T* G, const T* Y, long long R, int C, int CB,
+                                                                const float* scale, const float* shift,
+                                                                const float* mean, const float* rstd, int act,
+                                                                const float* gate, const float* dpool,
+                                                                int rows_per_img, float* part) {
+    __shared__ float red[256 * 8];
+    const int tid = threadIdx.x;
+    const RowMap m = make_rowmap(C, CB, blockIdx.y, tid);
+    f4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+    if (m.valid) {
+        const f4 sc = load4<float>(scale + m.c), sh = load4<float>(shift + m.c);
+        const f4 mu = load4<float>(mean + m.c), rs = load4<float>(rstd + m.c);
+        const bool writes = (act != MIA_ACT_NONE) || gate || dpool;
+        for (long long r = (long long)blockIdx.x * m.npt + m.pt; r < R; r += (long long)gridDim.x * m.npt) {
+            const size_t idx = (size_t)r * C + m.c;
+            f4 g = load4<T>(G + idx);
+            const f4 y = load4<T>(Y + idx);
+            if (gate) {
+                const f4 gt = load4<float>(gate + (size_t)(r / rows_per_img) * C + m.c);
+                g.x *= gt.x; g.y *= gt.y; g.z *= gt.z; g.w *= gt.w;
+            }
+            if (dpool) {
+                const f4 dp = load4<float>(dpool + (size_t)(r / rows_per_img) * C + m.c);
+                g.x += dp.x; g.y += dp.y; g.z += dp.z; g.w += dp.w;
+            }
+            if (act == MIA_ACT_SILU) {
+                g.x *= silu_gradf_(y.x * sc.x + sh.x);
+                g.y *= silu_gradf_(y.y * sc.y + sh.y);
+                g.z *= silu_gradf_(y.z * sc.z + sh.z);
+                g.w *= silu_gradf_(y.w * sc.w + sh.w);
+            }
+            s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+            q.x += g.x * ((y.x - mu.x) * rs.x);
+            q.y += g.y * ((y.y - mu.y) * rs.y);
+            q.z += g.z * ((y.z - mu.z) * rs.z);
+            q.w += g.w * ((y.w - mu.w) * rs.w);
+            if (writes) store4<T>(G + idx, g);
+        }
+    }
+    block_colsum2(red, m, tid, s, q, part + ((size_t)blockIdx.x * 2 + 0) * C, part + ((size_t)blockIdx.x * 2 + 1) * C);
+}
+
+extern "C" int mia_bn_act_bwd_reduce(int dtype, void* G, const void* Y, long long R, int C, const float* scale,
+                                     const float* shift, const float* mean, const float* rstd, int act,
+                                     const float* gate, const float* dpool, int rows_per_img, float* part,
+                                     int part_rows, void* stream) {
+    MIA_CHECK_ARG(G && Y && R > 0 && C > 0 && C % 4 == 0 && scale && shift && mean && rstd && part,
+                  "mia_bn_act_bwd_reduce: bad arguments");
+    MIA_CHECK_ARG(part_rows > 0 && part_rows <= 65535, "mia_bn_act_bwd_reduce: bad part_rows");
+    MIA_CHECK_ARG(!(gate || dpool) || rows_per_img > 0, "mia_bn_act_bwd_reduce: gate/dpool need rows_per_img");
+    int ncb, CB;
+    host_colblock(C, &ncb, &CB);
+    dim3 grid(part_rows, ncb);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (rows_per_img <= 0) rows_per_img = 1;
+    if (dtype == MIA_BF16)
+        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)G, (const bf16_t*)Y, R, C,
+                           CB, scale, shift, mean, rstd, act, gate, dpool, rows_per_img, part);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, (float*)G, (const float*)Y, R, C, CB,
+                           scale, shift, mean, rstd, act, gate, dpool, rows_per_img, part);
+    MIA_CHECK_LAUNCH("mia_bn_act_bwd_reduce");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise: out = a[c]*x + b[c]*y + d[c]   (y, b optional)  then act, then + res
+//   BN forward apply:  a=scale, d=shift               (act, residual optional)
+//   BN backward apply: a=ca, b=cb, d=cd with x=g, y=raw forward tensor
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void affine2_kernel(const T* X, const T* Y, const T* Res, T* Out, long long nvec,
+                                                      int C, const float* a, const float* b, const float* d, int act) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const size_t idx = (size_t)i * 4;
+        const int c = (int)(idx % C);
+        f4 x = load4<T>(X + idx);
+        const f4 av = load4<float>(a + c), dv = load4<float>(d + c);
+        f4 o = {x.x * av.x + dv.x, x.y * av.y + dv.y, x.z * av.z + dv.z, x.w * av.w + dv.w};
+        if (Y) {
+            const f4 y = load4<T>(Y + idx);
+            const f4 bv = load4<float>(b + c);
+            o.x += y.x * bv.x; o.y += y.y * bv.y; o.z += y.z * bv.z; o.w += y.w * bv.w;
+        }
+        if (act == MIA_ACT_SILU) {
+            o.x = siluf_(o.x); o.y = siluf_(o.y); o.z = siluf_(o.z); o.w = siluf_(o.w);
+        } else if (act == MIA_ACT_RELU) {
+            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        if (Res) {
+            const f4 r = load4<T>(Res + idx);
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        store4<T>(Out + idx, o);
+    }
+}
+
+extern "C" int mia_affine2(int dtype, const void* X, const void* Y, const void* Res, void* Out, long long R, int C,
+                           const float* a, const float* b, const float* d, int act, void* stream) {
+    MIA_CHECK_ARG(X && Out && a && d && R > 0 && C > 0 && C % 4 == 0, "mia_affine2: bad arguments");
+    MIA_CHECK_ARG(!Y || b, "mia_affine2: Y needs coefficient b");
+    const long long nvec = R * C / 4;
+    long long blocks = (nvec + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIA_BF16)
+        hipLaunchKernelGGL(affine2_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)X,
+                           (const bf16_t*)Y, (const bf16_t*)Res, (bf16_t*)Out, nvec, C, a, b, d, act);
+    else
+        hipLaunchKernelGGL(affine2_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)X,
+                           (const float*)Y, (const float*)Res, (float*)Out, nvec, C, a, b, d, act);
+    MIA_CHECK_LAUNCH("mia_affine2");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-image channel sums over H*W rows:  out[b][split][c] = sum_rows W(r,c) * silu(y*scale+shift)
+//   W = 1           squeeze-excite pooling (forward)
+//   W = dZ[r,c]     gradient w.r.t. the gate (backward)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void img_colsum_kernel(const T* Y, const T* Wt, int HW, int C, int CB, int splits,
+                                                         const float* scale, const float* shift, int act, float* out) {
+    __shared__ float red[256 * 8];
+    const int tid = threadIdx.x;
+    const RowMap m = make_rowmap(C, CB, blockIdx.y, tid);
+    const int b = blockIdx.x / splits, sp = blockIdx.x % splits;
+    const int rows_per_split = (HW + splits - 1) / splits;
+    const int r_begin = sp * rows_per_split;
+    const int r_end = (r_begin + rows_per_split) < HW ? (r_begin + rows_per_split) : HW;
+    f4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+    if (m.valid) {
+        f4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
+        if (scale) { sc = load4<float>(scale + m.c); sh = load4<float>(shift + m.c); }
+        for (int r = r_begin + m.pt; r < r_end; r += m.npt) {
+            const size_t idx = ((size_t)b * HW + r) * C + m.c;
+            f4 y = load4<T>(Y + idx);
+            y.x = y.x * sc.x + sh.x; y.y = y.y * sc.y + sh.y; y.z = y.z * sc.z + sh.z; y.w = y.w * sc.w + sh.w;
+            if (act == MIA_ACT_SILU) { y.x = siluf_(y.x); y.y = siluf_(y.y); y.z = siluf_(y.z); y.w = siluf_(y.w); }
+            if (Wt) {
+                const f4 w = load4<T>(Wt + idx);
+                y.x *= w.x; y.y *= w.y; y.z *= w.z; y.w *= w.w;
+            }
+            s.x += y.x; s.y += y.y; s.z += y.z; s.w += y.w;
+        }
+    }
+    block_colsum2(red, m, tid, s, q, out + ((size_t)b * splits + sp) * C, nullptr);
+}
+
+extern "C" int mia_img_colsum(int dtype, const void* Y, const void* Wt, int B, int HW, int C, const float* scale,
+                              const float* shift, int act, int splits, float* out, void* stream) {
+    MIA_CHECK_ARG(Y && out && B > 0 && HW > 0 && C > 0 && C % 4 == 0 && splits > 0 && splits <= HW,
+                  "mia_img_colsum: bad arguments");
+    MIA_CHECK_ARG(!(scale == nullptr) == !(shift == nullptr), "mia_img_colsum: scale/shift must come together");
+    int ncb, CB;
+    host_colblock(C, &ncb, &CB);
+    dim3 grid(B * splits, ncb);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIA_BF16)
+        hipLaunchKernelGGL(img_colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)Y, (const bf16_t*)Wt, HW, C,
+                           CB, splits, scale, shift, act, out);
+    else
+        hipLaunchKernelGGL(img_colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)Y, (const float*)Wt, HW, C, CB,
+                           splits, scale, shift, act, out);
+    MIA_CHECK_LAUNCH("mia_img_colsum");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// squeeze-excite gate: pooled -> FC(rd)+SiLU -> FC(C)+sigmoid.  One workgroup per image.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* pool_part, int splits, float inv_hw, int C,
+                                                          int RD, const float* Wr, const float* br, const float* We,
+                                                          const float* be, float* pooled, float* hpre, float* gate) {
+    extern __shared__ float sm[];
+    float* pl = sm;      // [C]
+    float* h = sm + C;   // [RD]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += pool_part[((size_t)b * splits + k) * C + c];
+        s *= inv_hw;
+        pl[c] = s;
+        pooled[(size_t)b * C + c] = s;
+    }
+    __syncthreads();
+    for (int j = wave; j < RD; j += 4) {
+        float d = 0.f;
+        for (int c = lane; c < C; c += 64) d += Wr[(size_t)j * C + c] * pl[c];
+        d = wave_sum(d);
+        if (lane == 0) {
+            const float pre = d + br[j];
+            hpre[(size_t)b * RD + j] = pre;
+            h[j] = siluf_(pre);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float d = be[c];
+        for (int j = 0; j < RD; ++j) d += We[(size_t)c * RD + j] * h[j];
+        gate[(size_t)b * C + c] = sigmoidf_(d);
+    }
+}
+
+extern "C" int mia_se_gate_fwd(const float* pool_part, int B, int splits, int HW, int C, int RD, const float* Wr,
+                               const float* br, const float* We, const float* be, float* pooled, float* hpre,
+                               float* gate, void* stream) {
+    MIA_CHECK_ARG(pool_part && Wr && br && We && be && pooled && hpre && gate && B > 0 && C > 0 && RD > 0 && HW > 0,
+                  "mia_se_gate_fwd: bad arguments");
+    const size_t lds = (size_t)(C + RD) * 4;
+    hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), pool_part,
+                       splits, 1.0f / (float)HW, C, RD, Wr, br, We, be, pooled, hpre, gate);
+    MIA_CHECK_LAUNCH("mia_se_gate_fwd");
+    return 0;
+}
+
+// backward through the gate for one image: dgate (summed partials) -> dpre2 [B,C], dpre1 [B,RD],
+// dpool [B,C] (already divided by HW: it is added to every pixel's gradient)
+__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* dgate_part, int splits, float inv_hw, int C,
+                                                          int RD, const float* Wr, const float* We, const float* gate,
+                                                          const float* hpre, float* dpre2, float* dpre1, float* dpool) {
+    extern __shared__ float sm[];
+    float* d2 = sm;      // [C]
+    float* d1 = sm + C;  // [RD]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += dgate_part[((size_t)b * splits + k) * C + c];
+        const float g = gate[(size_t)b * C + c];
+        const float v = s * g * (1.f - g);
+        d2[c] = v;
+        dpre2[(size_t)b * C + c] = v;
+    }
+    __syncthreads();
+    for (int j = wave; j < RD; j += 4) {
+        float d = 0.f;
+        for (int c = lane; c < C; c += 64) d += We[(size_t)c * RD + j] * d2[c];
+        d = wave_sum(d);
+        if (lane == 0) {
+            const float v = d * silu_gradf_(hpre[(size_t)b * RD + j]);
+            d1[j] = v;
+            dpre1[(size_t)b * RD + j] = v;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float d = 0.f;
+        for (int j = 0; j < RD; ++j) d += Wr[(size_t)j * C + c] * d1[j];
+        dpool[(size_t)b * C + c] = d * inv_hw;
+    }
+}
+
+// parameter gradients of the two FCs, summed over the batch (fixed order => reproducible)
+__global__ __launch_bounds__(256) void se_param_grad_kernel(int B, int C, int RD, const float* dpre2,
+                                                            const float* dpre1, const float* pooled, const float* hpre,
+                                                            float* dWr, float* dbr, float* dWe, float* dbe) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= C * RD) return;
+    // i = c*RD + j addresses We[c][j]; the same thread also produces Wr[j][c]
+    const int c = i / RD, j = i % RD;
+    float we = 0.f, wr = 0.f, bE = 0.f, bR = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float p2 = dpre2[(size_t)b * C + c], p1 = dpre1[(size_t)b * RD + j];
+        we += p2 * siluf_(hpre[(size_t)b * RD + j]);
+        wr += p1 * pooled[(size_t)b * C + c];
+        bE += p2;
+        bR += p1;
+    }
+    dWe[(size_t)c * RD + j] = we;
+    dWr[(size_t)j * C + c] = wr;
+    if (j == 0) dbe[c] = bE;
+    if (c == 0) dbr[j] = bR;
+}
+
+extern "C" int mia_se_gate_bwd(const float* dgate_part, int B, int splits, int HW, int C, int RD, const float* Wr,
+                               const float* We, const float* gate, const float* hpre, const float* pooled,
+                               float* dpre2, float* dpre1, float* dpool, float* dWr, float* dbr, float* dWe,
+                               float* dbe, void* stream) {
+    MIA_CHECK_ARG(dgate_part && Wr && We && gate && hpre && pooled && dpre2 && dpre1 && dpool && dWr && dbr && dWe &&
+                      dbe && B > 0 && C > 0 && RD > 0 && HW > 0,
+                  "mia_se_gate_bwd: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t lds = (size_t)(C + RD) * 4;
+    hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(256), lds, s, dgate_part, splits, 1.0f / (float)HW, C, RD, Wr,
+                       We, gate, hpre, dpre2, dpre1, dpool);
+    hipLaunchKernelGGL(se_param_grad_kernel, dim3(cdiv((long long)C * RD, 256)), dim3(256), 0, s, B, C, RD, dpre2,
+                       dpre1, pooled, hpre, dWr, dbr, dWe, dbe);
+    MIA_CHECK_LAUNCH("mia_se_gate_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stem: im2col of the 3x3 stride-2 pad-1 convolution. x NCHW fp32 [B,3,H,W] -> col [B*OH*OW, 32] (T);
+// column = ci*9 + kh*3 + kw, columns 27..31 zero. The stem conv is then one pointwise GEMM.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* x, int B, int H, int W, int OH, int OW, T* col) {
+    const long long total = (long long)B * OH * OW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ow = (int)(i % OW), oh = (int)((i / OW) % OH), b = (int)(i / ((long long)OW * OH));
+        float v[32];
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
+                    v[ci * 9 + kh * 3 + kw] = (ih >= 0 && ih < H && iw >= 0 && iw < W)
+                                                  ? x[(((size_t)b * 3 + ci) * H + ih) * W + iw]
+                                                  : 0.f;
+                }
+#pragma unroll
+        for (int k = 27; k < 32; ++k) v[k] = 0.f;
+        T* o = col + (size_t)i * 32;
+#pragma unroll
+        for (int k = 0; k < 32; k += 4) store4<T>(o + k, f4{v[k], v[k + 1], v[k + 2], v[k + 3]});
+    }
+}
+
+extern "C" int mia_stem_im2col(int dtype, const float* x, int B, int H, int W, void* col, void* stream) {
+    MIA_CHECK_ARG(x && col && B > 0 && H > 0 && W > 0, "mia_stem_im2col: bad arguments");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)B * OH * OW;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIA_BF16)
+        hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, x, B, H, W, OH, OW,
+                           (bf16_t*)col);
+    else
+        hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, x, B, H, W, OH, OW,
+                           (float*)col);
+    MIA_CHECK_LAUNCH("mia_stem_im2col");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight preparation: fp32 master [R][Cc] -> compute-dtype copy [R][ldd] and/or transpose [Cc][ldt],
+// zero-padded to the leading dimensions.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cast_pad_transpose_kernel(const float* src, int R, int Cc, T* dst, int ldd,
+                                                                 T* dstT, int ldt) {
+    const long long n1 = dst ? (long long)R * ldd : 0;
+    const long long n2 = dstT ? (long long)Cc * ldt : 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n1 + n2; i += (long long)gridDim.x * 256) {
+        if (i < n1) {
+            const int r = (int)(i / ldd), c = (int)(i % ldd);
+            dst[i] = from_f32<T>(c < Cc ? src[(size_t)r * Cc + c] : 0.f);
+        } else {
+            const long long k = i - n1;
+            const int c = (int)(k / ldt), r = (int)(k % ldt);
+            dstT[k] = from_f32<T>(r < R ? src[(size_t)r * Cc + c] : 0.f);
+        }
+    }
+}
+
+extern "C" int mia_cast_pad_transpose(int dtype, const float* src, int R, int Cc, void* dst, int ldd, void* dstT,
+                                      int ldt, void* stream) {
+    MIA_CHECK_ARG(src && R > 0 && Cc > 0 && (dst || dstT), "mia_cast_pad_transpose: bad arguments");
+    MIA_CHECK_ARG((!dst || ldd >= Cc) && (!dstT || ldt >= R), "mia_cast_pad_transpose: leading dims too small");
+    const long long n = (dst ? (long long)R * ldd : 0) + (dstT ? (long long)Cc * ldt : 0);
+    long long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIA_BF16)
+        hipLaunchKernelGGL(cast_pad_transpose_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, src, R, Cc,
+                           (bf16_t*)dst, ldd, (bf16_t*)dstT, ldt);
+    else
+        hipLaunchKernelGGL(cast_pad_transpose_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, src, R, Cc,
+                           (float*)dst, ldd, (float*)dstT, ldt);
+    MIA_CHECK_LAUNCH("mia_cast_pad_transpose");
+    return 0;
+}

@@ -1,0 +1,213 @@
+// Bandwidth-bound preprocessing kernels (gfx950): 8-bit bilinear resize + normalise, and the
+// zero-intensity slice filter (mask, ordered compaction, gather).
+//
+// The resize follows OpenCV's 8-bit INTER_LINEAR arithmetic exactly (11-bit fixed-point weights,
+// int32 horizontal pass, ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2)>>2 vertical pass), so results are
+// integers and can be held bit-exact to a CPU restatement; the normalise step is the two fp32
+// operations (x - 255*mean) * (1/(255*std)). Floating-point contraction is disabled in this file:
+// an fma in the coordinate computation would change which source pixel a destination maps to.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+struct LinCoef {
+    int s0, s1, w0, w1;
+};
+
+__device__ __forceinline__ LinCoef lin_coef(int d, int src, int dst) {
+    const double scale = 1.0 / ((double)dst / (double)src);
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f = f - (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= src - 1) { f = 0.f; s = src - 1; }
+    LinCoef c;
+    c.s0 = s;
+    c.s1 = (s + 1) < src ? (s + 1) : (src - 1);
+    c.w1 = (int)rintf(f * 2048.0f);
+    c.w0 = (int)rintf((1.0f - f) * 2048.0f);
+    return c;
+}
+
+// src u8 [N,h,w,ch] (ch = 1 or 3) -> dst f32 [N,3,oh,ow]
+__global__ __launch_bounds__(256) void resize_normalize_kernel(const uint8_t* src, int N, int h, int w, int ch,
+                                                               float* dst, int oh, int ow, float m0, float m1, float m2,
+                                                               float r0, float r1, float r2, int mode) {
+    const long long total = (long long)N * oh * ow;
+    const float mm[3] = {m0, m1, m2}, rr[3] = {r0, r1, r2};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ox = (int)(i % ow), oy = (int)((i / ow) % oh), n = (int)(i / ((long long)ow * oh));
+        const LinCoef cx = lin_coef(ox, w, ow), cy = lin_coef(oy, h, oh);
+        const uint8_t* img = src + (size_t)n * h * w * ch;
+        const uint8_t* p00 = img + ((size_t)cy.s0 * w + cx.s0) * ch;
+        const uint8_t* p01 = img + ((size_t)cy.s0 * w + cx.s1) * ch;
+        const uint8_t* p10 = img + ((size_t)cy.s1 * w + cx.s0) * ch;
+        const uint8_t* p11 = img + ((size_t)cy.s1 * w + cx.s1) * ch;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int cs = ch == 3 ? c : 0;
+            const int S0 = (int)p00[cs] * cx.w0 + (int)p01[cs] * cx.w1;
+            const int S1 = (int)p10[cs] * cx.w0 + (int)p11[cs] * cx.w1;
+            int v = ((cy.w0 * (S0 >> 4)) >> 16) + ((cy.w1 * (S1 >> 4)) >> 16);
+            v = (v + 2) >> 2;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            float o;
+            if (mode == 0) {
+                o = (float)v - mm[c];
+                o = o * rr[c];
+            } else {
+                o = (float)v / 255.0f;
+            }
+            dst[(((size_t)n * 3 + c) * oh + oy) * ow + ox] = o;
+        }
+    }
+}
+
+// mode 0: (x - 255*mean) * (1/(255*std));  mode 1: x / 255
+extern "C" int mia_resize_normalize_u8(const uint8_t* src, int N, int h, int w, int ch, float* dst, int oh, int ow,
+                                       const float* mean3, const float* std3, int mode, void* stream) {
+    MIA_CHECK_ARG(src && dst && N > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "mia_resize_normalize_u8: bad arguments");
+    MIA_CHECK_ARG(ch == 1 || ch == 3, "mia_resize_normalize_u8: channels must be 1 or 3, got %d", ch);
+    MIA_CHECK_ARG(mode == 1 || (mean3 && std3), "mia_resize_normalize_u8: normalise mode needs mean and std");
+    float m[3] = {0, 0, 0}, r[3] = {1, 1, 1};
+    if (mode == 0) {
+        for (int i = 0; i < 3; ++i) {
+            volatile float mv = mean3[i] * 255.0f;
+            volatile float sv = std3[i] * 255.0f;
+            volatile float rv = 1.0f / sv;
+            m[i] = mv;
+            r[i] = rv;
+        }
+    }
+    const long long total = (long long)N * oh * ow;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(resize_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), src, N, h, w, ch, dst, oh, ow, m[0], m[1], m[2], r[0],
+                       r[1], r[2], mode);
+    MIA_CHECK_LAUNCH("mia_resize_normalize_u8");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// zero-intensity slice filter
+// ------------------------------------------------------------------------------------------------
+// flags[z] |= (any element of slice z != 0). grid = (splits, N). kind: 0 integer bytes, 1 float32
+// (-0.0 equals zero, NaN does not).
+__global__ __launch_bounds__(256) void slice_nonzero_kernel(const uint8_t* vol, long long slice_bytes, int kind,
+                                                            int* flags) {
+    const long long z = blockIdx.y;
+    const uint8_t* base = vol + z * slice_bytes;
+    const uint32_t fmask = kind == 1 ? 0x7fffffffu : 0xffffffffu;
+    uint32_t acc = 0;
+    // head bytes up to 16-byte alignment, 16-byte body, tail
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(base);
+    long long head = (16 - (long long)(addr & 15)) & 15;
+    if (head > slice_bytes) head = slice_bytes;
+    const long long body = (slice_bytes - head) / 16;
+    const uint4* vb = reinterpret_cast<const uint4*>(base + head);
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < body; i += stride) {
+        const uint4 v = vb[i];
+        acc |= (v.x & fmask) | (v.y & fmask) | (v.z & fmask) | (v.w & fmask);
+    }
+    if (blockIdx.x == 0) {
+        // head [0, head) and tail [tail_begin, slice_bytes): fewer than 32 bytes in total, element-wise
+        const long long tail_begin = head + body * 16;
+        const int esz = kind == 1 ? 4 : 1;
+        for (long long o = (long long)threadIdx.x * esz; o < head; o += 256 * esz) {
+            if (kind == 1) acc |= (*reinterpret_cast<const uint32_t*>(base + o)) & fmask;
+            else acc |= base[o];
+        }
+        for (long long o = tail_begin + (long long)threadIdx.x * esz; o < slice_bytes; o += 256 * esz) {
+            if (kind == 1) acc |= (*reinterpret_cast<const uint32_t*>(base + o)) & fmask;
+            else acc |= base[o];
+        }
+    }
+    const unsigned long long any = __ballot(acc != 0);
+    if ((threadIdx.x & 63) == 0 && any) atomicOr(flags + z, 1);
+}
+
+// keep[z] = flag != 0; idx = ascending positions of kept slices; count[0] = how many. One workgroup.
+__global__ __launch_bounds__(256) void slice_compact_kernel(const int* flags, long long N, uint8_t* keep, int* idx,
+                                                            int* count) {
+    __shared__ int wsum[4];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (long long z0 = 0; z0 < N; z0 += 256) {
+        const long long z = z0 + tid;
+        const int f = (z < N) ? (flags[z] != 0) : 0;
+        const unsigned long long bal = __ballot(f);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wave; ++k) woff += wsum[k];
+        const int base = base_s;
+        if (z < N) {
+            keep[z] = (uint8_t)f;
+            if (f) idx[base + woff + before] = (int)z;
+        }
+        __syncthreads();
+        if (tid == 0) base_s = base + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (tid == 0) count[0] = base_s;
+}
+
+extern "C" int mia_zero_slice_filter(const void* vol, int elem_bytes, int is_float, long long n_slices,
+                                     long long slice_elems, int* flags_ws, uint8_t* keep, int* idx, int* count,
+                                     void* stream) {
+    MIA_CHECK_ARG(vol && flags_ws && keep && idx && count, "mia_zero_slice_filter: null argument");
+    MIA_CHECK_ARG(n_slices > 0 && n_slices <= 65535 && slice_elems > 0, "mia_zero_slice_filter: bad shape");
+    MIA_CHECK_ARG((elem_bytes == 1 || elem_bytes == 2 || elem_bytes == 4) && (!is_float || elem_bytes == 4),
+                  "mia_zero_slice_filter: unsupported element type (%d bytes, float=%d)", elem_bytes, is_float);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(flags_ws, 0, (size_t)n_slices * sizeof(int), s);
+    MIA_CHECK_ARG(e == hipSuccess, "mia_zero_slice_filter: memset failed: %s", hipGetErrorString(e));
+    const long long slice_bytes = slice_elems * elem_bytes;
+    long long splits = slice_bytes / (16 * 256 * 8);  // >= 8 vector loads per thread
+    if (splits < 1) splits = 1;
+    if (splits > 64) splits = 64;
+    hipLaunchKernelGGL(slice_nonzero_kernel, dim3((unsigned)splits, (unsigned)n_slices), dim3(256), 0, s,
+                       (const uint8_t*)vol, slice_bytes, is_float ? 1 : 0, flags_ws);
+    hipLaunchKernelGGL(slice_compact_kernel, dim3(1), dim3(256), 0, s, flags_ws, n_slices, keep, idx, count);
+    MIA_CHECK_LAUNCH("mia_zero_slice_filter");
+    return 0;
+}
+
+// out[k] = vol[idx[k]] for k < count[0]; grid = (chunks, n_slices) and rows beyond count exit at once.
+__global__ __launch_bounds__(256) void gather_slices_kernel(const uint8_t* vol, long long slice_bytes, const int* idx,
+                                                            const int* count, uint8_t* out) {
+    const int k = blockIdx.y;
+    if (k >= count[0]) return;
+    const uint8_t* src = vol + (long long)idx[k] * slice_bytes;
+    uint8_t* dst = out + (long long)k * slice_bytes;
+    const long long stride = (long long)gridDim.x * 256;
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+        const long long nv = slice_bytes / 16;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += stride)
+            reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+        for (long long o = nv * 16 + (long long)blockIdx.x * 256 + threadIdx.x; o < slice_bytes; o += stride)
+            dst[o] = src[o];
+    } else {
+        for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < slice_bytes; o += stride) dst[o] = src[o];
+    }
+}
+
+extern "C" int mia_gather_slices(const void* vol, int elem_bytes, long long n_slices, long long slice_elems,
+                                 const int* idx, const int* count, void* out, void* stream) {
+    MIA_CHECK_ARG(vol && idx && count && out, "mia_gather_slices: null argument");
+    MIA_CHECK_ARG(n_slices > 0 && n_slices <= 65535 && slice_elems > 0 && elem_bytes > 0, "mia_gather_slices: bad shape");
+    const long long slice_bytes = slice_elems * elem_bytes;
+    long long chunks = slice_bytes / (16 * 256 * 4);
+    if (chunks < 1) chunks = 1;
+    if (chunks > 64) chunks = 64;
+    hipLaunchKernelGGL(gather_slices_kernel, dim3((unsigned)chunks, (unsigned)n_slices), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), (const uint8_t*)vol, slice_bytes, idx, count,
+                       (uint8_t*)out);
+    MIA_CHECK_LAUNCH("mia_gather_slices");
+    return 0;
+}

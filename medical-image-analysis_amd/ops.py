@@ -1,0 +1,351 @@
+"""Thin tensor -> pointer wrappers over the C ABI (include/mia_hip.h) and the block-level autograd
+Functions built from them. Tensors are torch CUDA tensors used purely as device memory; every
+arithmetic step is a kernel of libmia_hip.so launched on torch's current HIP stream.
+"""
+import ctypes
+import math
+from typing import Optional
+
+import torch
+
+from ._lib import lib
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+MAX_PART = 1024
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("mia_amd kernels need tensors on an MI355X device; there is no CPU path")
+
+
+def part_rows(work_items: int) -> int:
+    return max(1, min(MAX_PART, int(work_items)))
+
+
+# ------------------------------------------------------------------------------------------------
+# primitive wrappers
+# ------------------------------------------------------------------------------------------------
+def gemm_nt(a2d, b, out2d=None, *, pscale=None, pshift=None, pro_act=ACT_NONE, gate=None, rows_per_img=0,
+            bias=None, epi_act=ACT_NONE, add=None, stats_rows=0, ldc=None):
+    """out[M,N] = pro(a)[M,K] @ b[N,K]^T ...; returns (out, part or None)."""
+    _require_cuda(a2d)
+    M, K = a2d.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and a2d.dtype == b.dtype, (a2d.shape, b.shape, a2d.dtype, b.dtype)
+    if out2d is None:
+        out2d = torch.empty((M, N), dtype=a2d.dtype, device=a2d.device)
+    part = None
+    if stats_rows:
+        part = torch.empty((stats_rows, 2, N), dtype=torch.float32, device=a2d.device)
+    lib().mia_gemm_nt(_DT[a2d.dtype], _p(a2d), a2d.stride(0), _p(b), b.stride(0), _p(out2d),
+                      ldc if ldc is not None else out2d.stride(0), _p(add), M, N, K, _p(pscale), _p(pshift), pro_act,
+                      _p(gate), rows_per_img, _p(bias), epi_act, _p(part), stats_rows, _stream())
+    return out2d, part
+
+
+def gemm_tn(g2d, x2d, *, pscale=None, pshift=None, pro_act=ACT_NONE, gate=None, rows_per_img=0, out=None):
+    """out[N,K] (fp32) = g[M,N]^T @ pro(x)[M,K]."""
+    M, N = g2d.shape
+    K = x2d.shape[1]
+    assert x2d.shape[0] == M and g2d.dtype == x2d.dtype
+    if out is None:
+        out = torch.zeros((N, K), dtype=torch.float32, device=g2d.device)
+    lib().mia_gemm_tn(_DT[g2d.dtype], _p(g2d), g2d.stride(0), _p(x2d), x2d.stride(0), _p(out), out.stride(0), M, N, K,
+                      _p(pscale), _p(pshift), pro_act, _p(gate), rows_per_img, _stream())
+    return out
+
+
+def dwconv_fwd(x, w, k, s, *, pscale=None, pshift=None, stats_rows=0):
+    B, H, W, C = x.shape
+    pad = (k - 1) // 2
+    OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    y = torch.empty((B, OH, OW, C), dtype=x.dtype, device=x.device)
+    part = torch.empty((stats_rows, 2, C), dtype=torch.float32, device=x.device) if stats_rows else None
+    lib().mia_dwconv_fwd(_DT[x.dtype], _p(x), B, H, W, C, _p(pscale), _p(pshift), _p(w), k, s, _p(y), _p(part),
+                         stats_rows, _stream())
+    return y, part
+
+
+def dwconv_bwd_data(dy, w, k, s, in_hw, *, yfwd=None, escale=None, eshift=None, emean=None, erstd=None, stats_rows=0):
+    B, OH, OW, C = dy.shape
+    H, W = in_hw
+    dx = torch.empty((B, H, W, C), dtype=dy.dtype, device=dy.device)
+    part = torch.empty((stats_rows, 2, C), dtype=torch.float32, device=dy.device) if stats_rows else None
+    lib().mia_dwconv_bwd_data(_DT[dy.dtype], _p(dy), B, H, W, C, _p(w), k, s, _p(dx), _p(yfwd), _p(escale),
+                              _p(eshift), _p(emean), _p(erstd), _p(part), stats_rows, _stream())
+    return dx, part
+
+
+def dwconv_bwd_weight(x, dy, k, s, *, pscale=None, pshift=None):
+    B, H, W, C = x.shape
+    dw = torch.zeros((C, 1, k, k), dtype=torch.float32, device=x.device)
+    lib().mia_dwconv_bwd_weight(_DT[x.dtype], _p(x), B, H, W, C, _p(pscale), _p(pshift), _p(dy), k, s, _p(dw),
+                                _stream())
+    return dw
+
+
+class BNState:
+    """The parameters/buffers of one BatchNorm layer plus mode; plain holder."""
+    __slots__ = ("weight", "bias", "running_mean", "running_var", "nbt", "momentum", "eps", "training")
+
+    def __init__(self, bn: torch.nn.Module):
+        self.weight, self.bias = bn.weight, bn.bias
+        self.running_mean, self.running_var, self.nbt = bn.running_mean, bn.running_var, bn.num_batches_tracked
+        self.momentum, self.eps = bn.momentum, bn.eps
+        self.training = bn.training or bn.running_mean is None
+
+
+def bn_finalize_fwd(part, count, bn: BNState):
+    C = bn.weight.shape[0]
+    dev = bn.weight.device
+    out = torch.empty((4, C), dtype=torch.float32, device=dev)
+    P = part.shape[0] if part is not None else 0
+    lib().mia_bn_finalize_fwd(_p(part), P, C, float(count), _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
+                              _p(bn.running_var), _p(bn.nbt), float(bn.momentum), float(bn.eps),
+                              1 if bn.training else 0, _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _stream())
+    return out  # rows: scale, shift, mean, rstd
+
+
+def bn_finalize_bwd(part, count, gamma, stats, training):
+    C = gamma.shape[0]
+    coef = torch.empty((5, C), dtype=torch.float32, device=gamma.device)  # dgamma, dbeta, ca, cb, cd
+    lib().mia_bn_finalize_bwd(_p(part), part.shape[0], C, float(count), _p(gamma), _p(stats[2]), _p(stats[3]),
+                              1 if training else 0, _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _p(coef[4]),
+                              _stream())
+    return coef
+
+
+def bn_act_bwd_reduce(g, y, stats, act, *, gate=None, dpool=None, rows_per_img=0):
+    """In place on g; returns partials."""
+    C = g.shape[-1]
+    R = g.numel() // C
+    rows = part_rows((R + 63) // 64)
+    part = torch.empty((rows, 2, C), dtype=torch.float32, device=g.device)
+    lib().mia_bn_act_bwd_reduce(_DT[g.dtype], _p(g), _p(y), R, C, _p(stats[0]), _p(stats[1]), _p(stats[2]),
+                                _p(stats[3]), act, _p(gate), _p(dpool), rows_per_img, _p(part), rows, _stream())
+    return part
+
+
+def affine2(x, a, d, *, y=None, b=None, res=None, act=ACT_NONE, out=None):
+    C = x.shape[-1]
+    R = x.numel() // C
+    if out is None:
+        out = torch.empty_like(x)
+    lib().mia_affine2(_DT[x.dtype], _p(x), _p(y), _p(res), _p(out), R, C, _p(a), _p(b), _p(d), act, _stream())
+    return out
+
+
+def img_colsum(y, wt, scale, shift, act):
+    B, H, W, C = y.shape
+    HW = H * W
+    splits = max(1, min(16, HW // 1024))
+    out = torch.empty((B, splits, C), dtype=torch.float32, device=y.device)
+    lib().mia_img_colsum(_DT[y.dtype], _p(y), _p(wt), B, HW, C, _p(scale), _p(shift), act, splits, _p(out), _stream())
+    return out
+
+
+def se_gate_fwd(pool_part, hw, wr, br, we, be):
+    B, splits, C = pool_part.shape
+    RD = wr.shape[0]
+    dev = pool_part.device
+    pooled = torch.empty((B, C), dtype=torch.float32, device=dev)
+    hpre = torch.empty((B, RD), dtype=torch.float32, device=dev)
+    gate = torch.empty((B, C), dtype=torch.float32, device=dev)
+    lib().mia_se_gate_fwd(_p(pool_part), B, splits, hw, C, RD, _p(wr), _p(br), _p(we), _p(be), _p(pooled), _p(hpre),
+                          _p(gate), _stream())
+    return pooled, hpre, gate
+
+
+def se_gate_bwd(dgate_part, hw, wr, we, gate, hpre, pooled):
+    B, splits, C = dgate_part.shape
+    RD = wr.shape[0]
+    dev = dgate_part.device
+    dpre2 = torch.empty((B, C), dtype=torch.float32, device=dev)
+    dpre1 = torch.empty((B, RD), dtype=torch.float32, device=dev)
+    dpool = torch.empty((B, C), dtype=torch.float32, device=dev)
+    dwr = torch.empty_like(wr)
+    dbr = torch.empty((RD,), dtype=torch.float32, device=dev)
+    dwe = torch.empty_like(we)
+    dbe = torch.empty((C,), dtype=torch.float32, device=dev)
+    lib().mia_se_gate_bwd(_p(dgate_part), B, splits, hw, C, RD, _p(wr), _p(we), _p(gate), _p(hpre), _p(pooled),
+                          _p(dpre2), _p(dpre1), _p(dpool), _p(dwr), _p(dbr), _p(dwe), _p(dbe), _stream())
+    return dpool, dwr, dbr, dwe, dbe
+
+
+def stem_im2col(x, dtype):
+    B, _, H, W = x.shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    col = torch.empty((B * OH * OW, 32), dtype=dtype, device=x.device)
+    lib().mia_stem_im2col(_DT[dtype], _p(x), B, H, W, _p(col), _stream())
+    return col, OH, OW
+
+
+def cast_weight(w2d, dtype, *, pad_to=None, want=True, want_t=False):
+    """fp32 [R,Cc] -> (copy [R,ld] or None, transpose [Cc,R] or None) in the compute dtype."""
+    R, Cc = w2d.shape
+    ld = pad_to or Cc
+    dst = dstT = None
+    if want:
+        if dtype == torch.float32 and ld == Cc:
+            dst = w2d
+        else:
+            dst = torch.empty((R, ld), dtype=dtype, device=w2d.device)
+    if want_t:
+        dstT = torch.empty((Cc, R), dtype=dtype, device=w2d.device)
+    if (dst is not None and dst is not w2d) or dstT is not None:
+        lib().mia_cast_pad_transpose(_DT[dtype], _p(w2d), R, Cc, _p(dst if dst is not w2d else None), ld, _p(dstT), R,
+                                     _stream())
+    return dst, dstT
+
+
+# ------------------------------------------------------------------------------------------------
+# block-level autograd Functions. Inputs/outputs are NHWC tensors in the compute dtype.
+# `cfg` is a small python object carried outside autograd (BN buffers, geometry, flags).
+# ------------------------------------------------------------------------------------------------
+def _w2d(w):
+    return w.detach().reshape(w.shape[0], -1)
+
+
+class StemFn(torch.autograd.Function):
+    """conv_stem (3x3 s2) -> bn1 -> SiLU, from an NCHW fp32 image to an NHWC activation."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, cfg):
+        B = x.shape[0]
+        x = x.contiguous().float()
+        col, OH, OW = stem_im2col(x, cfg.dtype)
+        wp, _ = cast_weight(_w2d(w), cfg.dtype, pad_to=32)
+        M = B * OH * OW
+        bn = cfg.bn
+        rows = part_rows((M + 255) // 256) if bn.training else 0
+        y0, part = gemm_nt(col, wp, stats_rows=rows)
+        st = bn_finalize_fwd(part, M, bn)
+        out = affine2(y0, st[0], st[1], act=ACT_SILU).view(B, OH, OW, -1)
+        ctx.cfg, ctx.training = cfg, bn.training
+        ctx.save_for_backward(col, y0, st, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        col, y0, st, gamma = ctx.saved_tensors
+        g = dout.contiguous().view(y0.shape).clone()
+        M = y0.shape[0]
+        part = bn_act_bwd_reduce(g, y0, st, ACT_SILU)
+        coef = bn_finalize_bwd(part, M, gamma, st, ctx.training)
+        affine2(g, coef[2], coef[4], y=y0, b=coef[3], out=g)
+        dw = gemm_tn(g, col)  # [40, 32]
+        return None, dw[:, :27].reshape(-1, 3, 3, 3), coef[0], coef[1], None
+
+
+class MBConvFn(torch.autograd.Function):
+    """One EfficientNet block. cfg.kind 'ir': conv_pw-bn1-SiLU-conv_dw-bn2-SiLU-SE-conv_pwl-bn3(+x);
+    'ds': conv_dw-bn1-SiLU-SE-conv_pw-bn2(+x)."""
+
+    @staticmethod
+    def forward(ctx, x, w_exp, g1, b1, w_dw, g2, b2, w_ser, b_ser, w_see, b_see, w_proj, g3, b3, cfg):
+        x = x.contiguous()
+        B, H, W, Cin = x.shape
+        dt = x.dtype
+        k, s = cfg.k, cfg.s
+        training = cfg.bn_dw.training
+        # ---- expansion (ir only) ----
+        if cfg.kind == "ir":
+            M = B * H * W
+            wexp, _ = cast_weight(_w2d(w_exp), dt)
+            y1, part = gemm_nt(x.view(M, Cin), wexp, stats_rows=part_rows((M + 127) // 128) if training else 0)
+            st1 = bn_finalize_fwd(part, M, cfg.bn_exp)
+            y1 = y1.view(B, H, W, -1)
+            dw_in, dw_sc, dw_sh = y1, st1[0], st1[1]
+        else:
+            y1, st1 = None, None
+            dw_in, dw_sc, dw_sh = x, None, None
+        Cm = dw_in.shape[-1]
+        # ---- depthwise ----
+        pad = (k - 1) // 2
+        OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+        M2 = B * OH * OW
+        wdw = w_dw.detach().reshape(Cm, k * k)
+        y2, part = dwconv_fwd(dw_in, wdw, k, s, pscale=dw_sc, pshift=dw_sh,
+                              stats_rows=part_rows(B * ((OH * OW + 127) // 128)) if training else 0)
+        st2 = bn_finalize_fwd(part, M2, cfg.bn_dw)
+        # ---- squeeze-excite ----
+        pool_part = img_colsum(y2, None, st2[0], st2[1], ACT_SILU)
+        wr, we = _w2d(w_ser), _w2d(w_see)
+        pooled, hpre, gate = se_gate_fwd(pool_part, OH * OW, wr, b_ser.detach(), we, b_see.detach())
+        # ---- projection ----
+        wproj, _ = cast_weight(_w2d(w_proj), dt)
+        y3, part = gemm_nt(y2.view(M2, Cm), wproj, pscale=st2[0], pshift=st2[1], pro_act=ACT_SILU, gate=gate,
+                           rows_per_img=OH * OW, stats_rows=part_rows((M2 + 127) // 128) if training else 0)
+        st3 = bn_finalize_fwd(part, M2, cfg.bn_proj)
+        Co = y3.shape[1]
+        y3 = y3.view(B, OH, OW, Co)
+        out = affine2(y3, st3[0], st3[1], res=x if cfg.has_skip else None)
+        ctx.cfg, ctx.training = cfg, training
+        ctx.save_for_backward(x, y1, st1, y2, st2, y3, st3, pooled, hpre, gate, w_exp, g1, w_dw, g2, w_ser, w_see,
+                              w_proj, g3)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x, y1, st1, y2, st2, y3, st3, pooled, hpre, gate, w_exp, g1, w_dw, g2, w_ser, w_see, w_proj,
+         g3) = ctx.saved_tensors
+        cfg, training = ctx.cfg, ctx.training
+        dout = dout.contiguous()
+        B, H, W, Cin = x.shape
+        _, OH, OW, Cm = y2.shape
+        Co = y3.shape[-1]
+        M, M2 = B * H * W, B * OH * OW
+        dt = x.dtype
+        k, s = cfg.k, cfg.s
+        # ---- bn3 (no activation) ----
+        part = bn_act_bwd_reduce(dout, y3, st3, ACT_NONE)
+        c3 = bn_finalize_bwd(part, M2, g3, st3, training)
+        dy3 = affine2(dout, c3[2], c3[4], y=y3, b=c3[3]).view(M2, Co)
+        # ---- projection: weight and data gradients ----
+        dwproj = gemm_tn(dy3, y2.view(M2, Cm), pscale=st2[0], pshift=st2[1], pro_act=ACT_SILU, gate=gate,
+                         rows_per_img=OH * OW)
+        _, wprojT = cast_weight(_w2d(w_proj), dt, want=False, want_t=True)  # [Cm, Co]
+        dz, _ = gemm_nt(dy3, wprojT)
+        dz = dz.view(B, OH, OW, Cm)
+        # ---- squeeze-excite backward ----
+        dgate_part = img_colsum(y2, dz, st2[0], st2[1], ACT_SILU)
+        wr, we = _w2d(w_ser), _w2d(w_see)
+        dpool, dwr, dbr, dwe, dbe = se_gate_bwd(dgate_part, OH * OW, wr, we, gate, hpre, pooled)
+        # ---- bn after depthwise (+SiLU) ----
+        part = bn_act_bwd_reduce(dz, y2, st2, ACT_SILU, gate=gate, dpool=dpool, rows_per_img=OH * OW)
+        c2 = bn_finalize_bwd(part, M2, g2, st2, training)
+        dy2 = affine2(dz, c2[2], c2[4], y=y2, b=c2[3], out=dz)
+        wdw = w_dw.detach().reshape(Cm, k * k)
+        rows_in = part_rows(B * ((H * W + 127) // 128))
+        if cfg.kind == "ir":
+            # depthwise data gradient with fused silu' and bn1 partials
+            g1t, part = dwconv_bwd_data(dy2, wdw, k, s, (H, W), yfwd=y1, escale=st1[0], eshift=st1[1], emean=st1[2],
+                                        erstd=st1[3], stats_rows=rows_in)
+            ddw = dwconv_bwd_weight(y1, dy2, k, s, pscale=st1[0], pshift=st1[1])
+            c1 = bn_finalize_bwd(part, M, g1, st1, training)
+            dy1 = affine2(g1t, c1[2], c1[4], y=y1, b=c1[3], out=g1t).view(M, Cm)
+            dwexp = gemm_tn(dy1, x.view(M, Cin))
+            _, wexpT = cast_weight(_w2d(w_exp), dt, want=False, want_t=True)  # [Cin, Cm]
+            dx, _ = gemm_nt(dy1, wexpT, add=dout.view(M, Cin) if cfg.has_skip else None)
+            dx = dx.view(B, H, W, Cin)
+            return (dx, dwexp.view_as(w_exp), c1[0], c1[1], ddw, c2[0], c2[1], dwr.view_as(w_ser), dbr,
+                    dwe.view_as(w_see), dbe, dwproj.view_as(w_proj), c3[0], c3[1], None)
+        # ds block: the depthwise conv reads the block input directly
+        dx, _ = dwconv_bwd_data(dy2, wdw, k, s, (H, W))
+        ddw = dwconv_bwd_weight(x, dy2, k, s)
+        if cfg.has_skip:
+            one = torch.ones((Cin,), dtype=torch.float32, device=dx.device)
+            affine2(dx, one, torch.zeros_like(one), res=dout, out=dx)
+        return (dx, None, None, None, ddw, c2[0], c2[1], dwr.view_as(w_ser), dbr, dwe.view_as(w_see), dbe,
+                dwproj.view_as(w_proj), c3[0], c3[1], None)

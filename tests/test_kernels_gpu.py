@@ -1,0 +1,284 @@
+"""GPU parity tests of the individual gfx950 kernels, called through the C ABI (ctypes), against plain
+PyTorch fp32 references of the same op. Integer/byte kernels must be bit-exact; floating-point kernels
+are held to the tolerances written in each test (relative to the reference tensor's largest magnitude)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import mia_amd  # noqa: E402,F401
+from mia_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def tol(dtype, f32=2e-5, bf16=2e-2):
+    return f32 if dtype == torch.float32 else bf16
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def test_library_targets_this_device():
+    mia_amd.lib().mia_check_device()
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(300, 24, 40), (1000, 144, 24), (777, 32, 192), (513, 48, 288), (260, 136, 816),
+                                   (200, 384, 2304), (129, 232, 136), (64, 512, 384), (130, 4, 512)])
+def test_gemm_nt_plain(dtype, M, N, K):
+    a, b = rnd(M, K, seed=1, dtype=dtype), rnd(N, K, seed=2, scale=K ** -0.5, dtype=dtype)
+    out, _ = ops.gemm_nt(a, b)
+    ref = a.float() @ b.float().t()
+    assert relerr(out.float(), ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,hw", [(2 * 361, 136, 816, 361), (3 * 100, 32, 192, 100), (4 * 49, 384, 2304, 49)])
+def test_gemm_nt_prologue_gate_stats(dtype, M, N, K, hw):
+    a, b = rnd(M, K, seed=1, dtype=dtype), rnd(N, K, seed=2, scale=K ** -0.5, dtype=dtype)
+    sc, sh = rnd(K, seed=3).abs() + 0.5, rnd(K, seed=4, scale=0.3)
+    gate = torch.sigmoid(rnd(M // hw, K, seed=5))
+    rows = 7
+    out, part = ops.gemm_nt(a, b, pscale=sc, pshift=sh, pro_act=ops.ACT_SILU, gate=gate, rows_per_img=hw,
+                            stats_rows=rows)
+    ap = F.silu(a.float() * sc + sh) * gate.repeat_interleave(hw, 0)
+    if dtype == torch.bfloat16:
+        ap = ap.bfloat16().float()
+    ref = ap @ b.float().t()
+    assert relerr(out.float(), ref) < tol(dtype)
+    s = part.sum(0)
+    assert relerr(s[0], ref.sum(0)) < tol(dtype, 1e-4)
+    assert relerr(s[1], (ref * ref).sum(0)) < tol(dtype, 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_nt_bias_relu_add(dtype):
+    M, N, K = 300, 512, 384
+    a, b = rnd(M, K, seed=1, dtype=dtype), rnd(N, K, seed=2, scale=K ** -0.5, dtype=dtype)
+    bias, add = rnd(N, seed=3), rnd(M, N, seed=4, dtype=dtype)
+    out, _ = ops.gemm_nt(a, b, bias=bias, epi_act=ops.ACT_RELU, add=add)
+    ref = F.relu(a.float() @ b.float().t() + bias)
+    if dtype == torch.bfloat16:
+        ref = ref.bfloat16().float()
+    ref = ref + add.float()
+    assert relerr(out.float(), ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(3000, 144, 24), (1000, 32, 192), (500, 136, 816), (300, 2304, 384),
+                                   (200, 384, 2304), (128, 512, 384), (5000, 40, 32)])
+def test_gemm_tn(dtype, M, N, K):
+    g, x = rnd(M, N, seed=1, dtype=dtype), rnd(M, K, seed=2, dtype=dtype)
+    out = ops.gemm_tn(g, x)
+    ref = g.float().t() @ x.float()
+    assert relerr(out, ref) < tol(dtype, 2e-5, 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_tn_prologue_gate(dtype):
+    hw, B, N, K = 100, 5, 48, 288
+    M = B * hw
+    g, x = rnd(M, N, seed=1, dtype=dtype), rnd(M, K, seed=2, dtype=dtype)
+    sc, sh = rnd(K, seed=3).abs() + 0.5, rnd(K, seed=4, scale=0.3)
+    gate = torch.sigmoid(rnd(B, K, seed=5))
+    out = ops.gemm_tn(g, x, pscale=sc, pshift=sh, pro_act=ops.ACT_SILU, gate=gate, rows_per_img=hw)
+    xp = F.silu(x.float() * sc + sh) * gate.repeat_interleave(hw, 0)
+    if dtype == torch.bfloat16:
+        xp = xp.bfloat16().float()
+    ref = g.float().t() @ xp
+    assert relerr(out, ref) < tol(dtype, 2e-5, 1e-2)
+
+
+# ------------------------------------------------------------------ depthwise
+DW_CASES = [(3, 1, 2, 19, 19, 96), (3, 2, 2, 38, 38, 288), (5, 1, 2, 19, 19, 136), (5, 2, 2, 19, 19, 816),
+            (5, 2, 1, 75, 75, 192), (3, 1, 1, 150, 150, 40), (3, 2, 1, 150, 150, 144), (3, 1, 3, 10, 10, 2304),
+            (5, 1, 3, 10, 10, 1392), (3, 1, 2, 2, 2, 24), (5, 2, 2, 4, 4, 48)]
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k,s,B,H,W,C", DW_CASES)
+def test_dwconv_fwd(dtype, k, s, B, H, W, C):
+    x = rnd(B, H, W, C, seed=1, dtype=dtype)
+    w = rnd(C, 1, k, k, seed=2, scale=1.0 / k)
+    sc, sh = rnd(C, seed=3).abs() + 0.5, rnd(C, seed=4, scale=0.3)
+    rows = 5
+    y, part = ops.dwconv_fwd(x, w.reshape(C, k * k), k, s, pscale=sc, pshift=sh, stats_rows=rows)
+    a = F.silu(x.float() * sc + sh)
+    if dtype == torch.bfloat16:
+        a = a.bfloat16().float()
+    ref = nhwc(F.conv2d(nchw(a), w, None, s, (k - 1) // 2, 1, C))
+    assert y.shape == ref.shape
+    assert relerr(y.float(), ref) < tol(dtype)
+    st = part.sum(0)
+    assert relerr(st[0], ref.sum((0, 1, 2))) < tol(dtype, 1e-4)
+    assert relerr(st[1], (ref * ref).sum((0, 1, 2))) < tol(dtype, 1e-4)
+    # no prologue
+    y2, _ = ops.dwconv_fwd(x, w.reshape(C, k * k), k, s)
+    ref2 = nhwc(F.conv2d(nchw(x.float()), w, None, s, (k - 1) // 2, 1, C))
+    assert relerr(y2.float(), ref2) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k,s,B,H,W,C", DW_CASES)
+def test_dwconv_bwd(dtype, k, s, B, H, W, C):
+    pad = (k - 1) // 2
+    x = rnd(B, H, W, C, seed=1, dtype=dtype)
+    w = rnd(C, 1, k, k, seed=2, scale=1.0 / k)
+    sc, sh = rnd(C, seed=3).abs() + 0.5, rnd(C, seed=4, scale=0.3)
+    OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    dy = rnd(B, OH, OW, C, seed=5, dtype=dtype)
+    # reference through autograd: a = silu(x*sc+sh); y = dw(a)
+    xr = x.float().clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    z = xr * sc + sh
+    a = F.silu(z)
+    a.retain_grad()
+    yref = F.conv2d(a.permute(0, 3, 1, 2), wr, None, s, pad, 1, C)
+    yref.backward(dy.float().permute(0, 3, 1, 2))
+    # plain data gradient
+    dx, _ = ops.dwconv_bwd_data(dy, w.reshape(C, k * k), k, s, (H, W))
+    assert relerr(dx.float(), a.grad) < tol(dtype)
+    # fused epilogue: g = dA * silu'(z) and its partial sums
+    mean, rstd = rnd(C, seed=6, scale=0.2), rnd(C, seed=7).abs() + 0.5
+    g, part = ops.dwconv_bwd_data(dy, w.reshape(C, k * k), k, s, (H, W), yfwd=x, escale=sc, eshift=sh, emean=mean,
+                                  erstd=rstd, stats_rows=4)
+    gref = xr.grad / sc  # d/dz
+    assert relerr(g.float(), gref) < tol(dtype)
+    st = part.sum(0)
+    xhat = (x.float() - mean) * rstd
+    assert relerr(st[0], gref.sum((0, 1, 2))) < tol(dtype, 1e-4, 3e-2)
+    assert relerr(st[1], (gref * xhat).sum((0, 1, 2))) < tol(dtype, 1e-4, 3e-2)
+    # weight gradient
+    dw = ops.dwconv_bwd_weight(x, dy, k, s, pscale=sc, pshift=sh)
+    assert relerr(dw, wr.grad) < tol(dtype, 5e-5, 2e-2)
+
+
+# ------------------------------------------------------------------ BN / SE / elementwise
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_finalize_fwd_matches_torch(training):
+    C, R = 136, 4000
+    y = rnd(R, C, seed=1) * 2 + 0.5
+    bn = torch.nn.BatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(rnd(C, seed=2).abs() + 0.5)
+        bn.bias.copy_(rnd(C, seed=3))
+        bn.running_mean.copy_(rnd(C, seed=4) * 0.1)
+        bn.running_var.copy_(rnd(C, seed=5).abs() + 0.5)
+    bn.train(training)
+    ref_bn = torch.nn.BatchNorm2d(C).to(DEV)
+    ref_bn.load_state_dict(bn.state_dict())
+    ref_bn.train(training)
+    parts = torch.stack([torch.stack([c.sum(0), (c * c).sum(0)]) for c in y.chunk(8, 0)])  # [8,2,C]
+    st = ops.bn_finalize_fwd(parts.contiguous(), R, ops.BNState(bn))
+    out = y * st[0] + st[1]
+    ref = ref_bn(y.t().reshape(1, C, R, 1)).reshape(C, R).t()
+    assert relerr(out, ref) < 1e-5
+    assert relerr(bn.running_mean, ref_bn.running_mean) < 1e-5
+    assert relerr(bn.running_var, ref_bn.running_var) < 1e-5
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,hw,B", [(144, 100, 3), (1392, 25, 2), (40, 900, 2)])
+def test_bn_silu_gate_backward_chain(dtype, C, hw, B):
+    """reduce -> finalize -> apply reproduces autograd of  a = silu(bn(y)) ; loss = sum(dZ * a * gate) + sum(dpool*mean_hw(a))."""
+    R = B * hw
+    y = rnd(R, C, seed=1, dtype=dtype)
+    dz = rnd(R, C, seed=2, dtype=dtype)
+    gamma, beta = rnd(C, seed=3).abs() + 0.5, rnd(C, seed=4, scale=0.3)
+    gate = torch.sigmoid(rnd(B, C, seed=5))
+    dpool = rnd(B, C, seed=6, scale=0.01)
+    yr = y.float().clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    mean, var = yr.mean(0), yr.var(0, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    a = F.silu((yr - mean) * rstd * gr + br)
+    loss = (dz.float() * a * gate.repeat_interleave(hw, 0)).sum() + (dpool.repeat_interleave(hw, 0) * a).sum()
+    loss.backward()
+    st = torch.stack([gamma * rstd.detach(), beta - mean.detach() * gamma * rstd.detach(), mean.detach(),
+                      rstd.detach()]).contiguous()
+    g = dz.clone()
+    part = ops.bn_act_bwd_reduce(g, y, st, ops.ACT_SILU, gate=gate, dpool=dpool, rows_per_img=hw)
+    coef = ops.bn_finalize_bwd(part, R, gamma, st, True)
+    dy = ops.affine2(g, coef[2], coef[4], y=y, b=coef[3])
+    assert relerr(dy.float(), yr.grad) < tol(dtype, 5e-5, 3e-2)
+    assert relerr(coef[0], gr.grad) < tol(dtype, 5e-5, 3e-2)
+    assert relerr(coef[1], br.grad) < tol(dtype, 5e-5, 3e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_affine2_and_img_colsum(dtype):
+    B, H, W, C = 3, 37, 41, 144
+    x, res = rnd(B, H, W, C, seed=1, dtype=dtype), rnd(B, H, W, C, seed=2, dtype=dtype)
+    a, d = rnd(C, seed=3), rnd(C, seed=4)
+    out = ops.affine2(x, a, d, res=res, act=ops.ACT_SILU)
+    ref = F.silu(x.float() * a + d) + res.float()
+    assert relerr(out.float(), ref) < tol(dtype)
+    ps = ops.img_colsum(x, None, a, d, ops.ACT_SILU)
+    assert relerr(ps.sum(1), F.silu(x.float() * a + d).sum((1, 2))) < tol(dtype, 1e-5, 1e-3)
+    ps2 = ops.img_colsum(x, res, a, d, ops.ACT_SILU)
+    assert relerr(ps2.sum(1), (F.silu(x.float() * a + d) * res.float()).sum((1, 2))) < tol(dtype, 1e-5, 1e-3)
+
+
+@pytest.mark.parametrize("C,RD,B,hw", [(144, 6, 4, 100), (2304, 96, 3, 49), (40, 10, 2, 400)])
+def test_se_gate_fwd_bwd(C, RD, B, hw):
+    pool_part = rnd(B, 3, C, seed=1)
+    wr, br = rnd(RD, C, seed=2, scale=C ** -0.5), rnd(RD, seed=3, scale=0.1)
+    we, be = rnd(C, RD, seed=4, scale=RD ** -0.5), rnd(C, seed=5, scale=0.1)
+    pooled, hpre, gate = ops.se_gate_fwd(pool_part, hw, wr, br, we, be)
+    pp = pool_part.clone().requires_grad_(True)
+    wr_, br_, we_, be_ = [t.clone().requires_grad_(True) for t in (wr, br, we, be)]
+    p_ref = pp.sum(1) / hw
+    g_ref = torch.sigmoid(F.linear(F.silu(F.linear(p_ref, wr_, br_)), we_, be_))
+    assert relerr(gate, g_ref) < 1e-5 and relerr(pooled, p_ref) < 1e-5
+    dgate_part = rnd(B, 2, C, seed=6)
+    g_ref.backward(dgate_part.sum(1))
+    dpool, dwr, dbr, dwe, dbe = ops.se_gate_bwd(dgate_part, hw, wr, we, gate, hpre, pooled)
+    # dpool is the per-pixel gradient: d/d(sum over pixels) / hw  == pp.grad of any split
+    assert relerr(dpool, pp.grad[:, 0]) < 1e-4
+    for mine, ref in ((dwr, wr_.grad), (dbr, br_.grad), (dwe, we_.grad), (dbe, be_.grad)):
+        assert relerr(mine, ref) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,W", [(300, 300), (64, 64), (33, 47)])
+def test_stem_im2col_gemm_equals_conv(dtype, H, W):
+    x = rnd(2, 3, H, W, seed=1)
+    w = rnd(40, 3, 3, 3, seed=2, scale=0.2)
+    col, OH, OW = ops.stem_im2col(x, dtype)
+    wp, _ = ops.cast_weight(w.reshape(40, 27), dtype, pad_to=32)
+    y, _ = ops.gemm_nt(col, wp)
+    xin = x if dtype == torch.float32 else x.bfloat16().float()
+    win = w if dtype == torch.float32 else w.bfloat16().float()
+    ref = F.conv2d(xin, win, None, 2, 1).permute(0, 2, 3, 1).reshape(-1, 40)
+    assert (OH, OW) == ((H - 1) // 2 + 1, (W - 1) // 2 + 1)
+    assert relerr(y.float(), ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cast_pad_transpose(dtype):
+    w = rnd(144, 24, seed=1)
+    d, dT = ops.cast_weight(w, dtype, pad_to=32, want=True, want_t=True)
+    assert torch.equal(d[:, :24].float(), w.to(dtype).float()) and float(d[:, 24:].abs().max()) == 0.0
+    assert torch.equal(dT.float(), w.to(dtype).float().t())

@@ -1,0 +1,160 @@
+"""GPU parity of blocks, trunk and whole model against the CPU oracle (oracle/effnet_b3.py) on identical
+seeded weights and inputs. Tolerances (north star): fp32 logits within 1e-4, gradients within 1e-3,
+both relative to the reference tensor's largest magnitude; bf16 within the tolerance stated per test."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import mia_amd  # noqa: E402,F401
+from mia_amd.src.model import create_foundation_model, load_model_weights_safely  # noqa: E402
+from mia_amd.trunk import EfficientNetB3Features, MBConv  # noqa: E402
+from oracle import effnet_b3 as O  # noqa: E402
+from seeding import randn, seeded_state_dict  # noqa: E402
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+BLOCKS = [("ds", 40, 24, 3, 1, 1, 30, 30), ("ds", 24, 24, 3, 1, 1, 17, 17), ("ir", 24, 32, 3, 2, 6, 30, 30),
+          ("ir", 32, 32, 3, 1, 6, 15, 15), ("ir", 32, 48, 5, 2, 6, 15, 15), ("ir", 136, 136, 5, 1, 6, 9, 9),
+          ("ir", 136, 232, 5, 2, 6, 9, 9), ("ir", 232, 384, 3, 1, 6, 5, 5)]
+
+
+@pytest.mark.parametrize("kind,cin,cout,k,s,e,H,W", BLOCKS)
+@pytest.mark.parametrize("train", [True, False])
+def test_block_matches_oracle_fp32(kind, cin, cout, k, s, e, H, W, train):
+    ref = O.DSBlock(cin, cout, k, s) if kind == "ds" else O.IRBlock(cin, cout, k, s, e)
+    sd = seeded_state_dict(ref, 5)
+    ref.load_state_dict(sd)
+    mine = MBConv(kind, cin, cout, k, s, e)
+    mine.load_state_dict(sd)
+    mine.cuda()
+    ref.train(train)
+    mine.train(train)
+    x = randn(6, 3, cin, H, W)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    xm = nhwc(x).cuda().requires_grad_(True)
+    ym = mine(xm)
+    assert relerr(ym.permute(0, 3, 1, 2), yr) < 2e-5
+    if not train:
+        return
+    g = randn(7, *yr.shape)
+    yr.backward(g)
+    ym.backward(nhwc(g).cuda())
+    assert relerr(xm.grad.permute(0, 3, 1, 2), xr.grad) < 2e-4
+    pr = dict(ref.named_parameters())
+    for n, p in mine.named_parameters():
+        assert p.grad is not None, n
+        assert relerr(p.grad, pr[n].grad) < 3e-4, n
+    br = dict(ref.named_buffers())
+    for n, b in mine.named_buffers():
+        if "running" in n:
+            assert relerr(b, br[n]) < 1e-5, n
+        if "num_batches" in n:
+            assert int(b) == int(br[n]), n
+
+
+def test_trunk_features_match_oracle_fp32_64px():
+    ref = O.EfficientNetB3Features()
+    sd = seeded_state_dict(ref, 9)
+    ref.load_state_dict(sd)
+    mine = EfficientNetB3Features()
+    mine.load_state_dict(sd)
+    mine.cuda()
+    x = randn(10, 2, 3, 64, 64)
+    ref.train()
+    mine.train()
+    fr = ref(x)
+    fm = mine(x.cuda())
+    assert [tuple(t.shape) for t in fm] == [tuple(t.shape) for t in fr]
+    for a, b in zip(fm, fr):
+        assert relerr(a, b) < 1e-4
+    ref.eval()
+    mine.eval()
+    with torch.no_grad():
+        fr, fm = ref(x), mine(x.cuda())
+    for a, b in zip(fm, fr):
+        assert relerr(a, b) < 1e-4
+
+
+def _pair(use_attention, seed=3):
+    heads = {"synthetic": 4}
+    ref = O.OracleFoundationModel(heads, dropout=0.0, use_attention=use_attention)
+    sd = seeded_state_dict(ref, seed)
+    ref.load_state_dict(sd)
+    mine = create_foundation_model(backbone="efficientnet_b3", pretrained=False, dropout=0.0,
+                                   classification_heads=heads, use_attention=use_attention)
+    missing, unexpected = load_model_weights_safely(mine, {"model_state_dict": sd})
+    assert not missing and not unexpected
+    return ref, mine.cuda()
+
+
+@pytest.mark.parametrize("use_attention", [True, False])
+def test_c1_step_fp32_batch8_300px(use_attention):
+    """Config C1: B3(+CBAM/MHA), 4 classes, batch 8 at 300x300, one fwd+bwd step, train-mode BN."""
+    torch.manual_seed(0)
+    ref, mine = _pair(use_attention)
+    x = randn(100, 8, 3, 300, 300)
+    y = torch.from_numpy(np.random.default_rng(0).integers(0, 4, 8))
+    ref.train()
+    mine.train()
+    lr = ref(x, "classification", "synthetic")
+    torch.nn.functional.cross_entropy(lr, y).backward()
+    lm = mine(x.cuda(), "classification", "synthetic")
+    torch.nn.functional.cross_entropy(lm.float(), y.cuda()).backward()
+    e = relerr(lm, lr)
+    print("logit relerr", e)
+    assert e < 1e-4
+    pr = dict(ref.named_parameters())
+    worst = (0.0, "")
+    for n, p in mine.named_parameters():
+        assert p.grad is not None, n
+        ge = relerr(p.grad, pr[n].grad)
+        worst = max(worst, (ge, n))
+    print("worst grad relerr", worst)
+    assert worst[0] < 1e-3, worst
+
+
+def test_bf16_tolerance_and_top1_on_fixed_set():
+    """bf16 storage / fp32 accumulate. Stated tolerance: logits within 6e-2 of the fp32 oracle relative to the
+    largest logit magnitude, and identical top-1 on every sample whose fp32 top-2 margin exceeds 10 % of the
+    largest logit (a fixed synthetic set of 32 images)."""
+    ref, mine = _pair(True, seed=4)
+    mine.set_compute_dtype(torch.bfloat16)
+    x = randn(101, 32, 3, 128, 128)
+    ref.eval()
+    mine.eval()
+    with torch.no_grad():
+        lr = ref(x, "classification", "synthetic")
+        lm = mine(x.cuda(), "classification", "synthetic").float().cpu()
+    scale = lr.abs().max()
+    assert ((lm - lr).abs().max() / scale).item() < 6e-2
+    top2 = lr.topk(2, dim=1).values
+    decided = (top2[:, 0] - top2[:, 1]) > 0.1 * scale
+    assert bool((lm.argmax(1)[decided] == lr.argmax(1)[decided]).all())
+
+
+def test_errors_and_api_contract():
+    mine = create_foundation_model(backbone="efficientnet_b3", pretrained=False, classification_heads={"a": 4})
+    mine.cuda()
+    x = torch.zeros(1, 3, 64, 64, device="cuda")
+    with pytest.raises(ValueError):
+        mine(x, "classification", "nope")
+    with pytest.raises(ValueError):
+        mine(x, "detection", "a")
+    mine.add_classification_head("alz", 4)
+    assert next(mine.classification_layers["alz"].parameters()).is_cuda
+    mine.eval()
+    with torch.no_grad():
+        assert tuple(mine(x, "classification", "alz").shape) == (1, 4)
+    f = mine.backbone(x)
+    assert [t.shape[1] for t in f] == [24, 32, 48, 136, 384]
