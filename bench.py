@@ -1,0 +1,179 @@
+"""Headline benchmark: train images/sec of EfficientNet-B3 + CBAM/attention head, 300x300, bf16, on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = forward + cross-entropy + backward (+ bucketed RCCL all-reduce) + AdamW on one synthetic batch that is
+already resident in HBM (128 MRI-shaped images per GPU: weak scaling, global batch 1024 at 8 GPUs). Prints ONE
+JSON line with the whole-job images/sec, the roofline of the dominant kernel family (HIP-event timed inside the
+timed region) and, at N=1, the CPU oracle timed on the host cores as a baseline.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (spec)
+FAMILIES = ["gemm_nt", "gemm_tn", "dwconv_fwd", "dwconv_bwd_data", "dwconv_bwd_weight", "bn_act_bwd_reduce",
+            "affine2", "img_colsum"]
+TRAIN_GFLOP_PER_IMG = {"b3_cbam": 11.00, "b3_plain": 10.60}   # 3 x forward FLOPs at 300x300
+
+
+def phantom_batch(n, seed):
+    """MRI-shaped uint8 grayscale 256x256: centred ellipse of N(110,40^2) clipped to [0,255], zero background."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:256, 0:256]
+    mask = ((yy - 128) / 107.0) ** 2 + ((xx - 128) / 85.0) ** 2 <= 1.0
+    img = np.clip(rng.normal(110, 40, (n, 256, 256)), 0, 255).astype(np.uint8)
+    return img * mask[None]
+
+
+def cpu_baseline(batch=8, steps=2, use_attention=True):
+    """The CPU oracle (plain PyTorch fp32 restatement) timed on the host cores: same step, bounded sample."""
+    from oracle.effnet_b3 import OracleFoundationModel
+    torch.manual_seed(0)
+    m = OracleFoundationModel({"synthetic": 4}, dropout=0.2, use_attention=use_attention).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-4)
+    x = torch.randn(batch, 3, 300, 300)
+    y = torch.randint(0, 4, (batch,))
+
+    def step():
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(m(x, "classification", "synthetic"), y).backward()
+        opt.step()
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{steps} fp32 train steps of batch {batch} at 300x300 after 1 warm-up "
+                                      f"(oracle/effnet_b3.py, torch {torch.__version__} CPU)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
+    ap.add_argument("--workload", default="b3_cbam", choices=["b3_cbam", "b3_plain"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="also print a per-family timing table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import mia_amd
+    from mia_amd import ops
+    from mia_amd import preprocess as PP
+    from mia_amd.ddp import GradReducer
+    from mia_amd.src.model import FoundationModel
+    mia_amd.lib().mia_check_device()
+
+    torch.manual_seed(1234)
+    use_attention = args.workload == "b3_cbam"
+    model = FoundationModel(backbone="efficientnet_b3", pretrained=False, dropout=0.2,
+                            classification_heads={"synthetic": 4}, use_attention=use_attention,
+                            compute_dtype=args.dtype).to(dev).train()
+    reducer = GradReducer(model.parameters())
+    reducer.broadcast_parameters(model)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+
+    # synthetic MRI-shaped batch, preprocessed on the device by the resize+normalise kernel, resident in HBM
+    raw = torch.from_numpy(phantom_batch(args.batch, 1234 + rank)).to(dev)
+    x = PP.resize_normalize(raw, (300, 300))
+    y = torch.from_numpy(np.random.default_rng(99 + rank).integers(0, 4, args.batch)).to(dev)
+
+    def step():
+        reducer.zero_grad()
+        logits = model(x, "classification", "synthetic")
+        loss = torch.nn.functional.cross_entropy(logits.float(), y)
+        loss.backward()
+        reducer.finish()
+        opt.step()
+        return loss
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up; the last warm-up step is event-timed per family to find the dominant one
+    for i in range(max(args.warmup, 1)):
+        if i == max(args.warmup, 1) - 1:
+            ops.KernelTimer.start(FAMILIES)
+        step()
+    table = ops.KernelTimer.stop()
+    dominant = max(table, key=lambda f: table[f][1]) if table else "gemm_nt"
+
+    barrier()
+    ops.KernelTimer.start([dominant])
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    rec = ops.KernelTimer.stop().get(dominant, (0, 0.0, 0))
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_v = float(loss.item())
+
+    if rank == 0:
+        ips = world * args.batch * args.steps / dt
+        launches, ms, nbytes = rec
+        achieved = (nbytes / (ms * 1e-3)) / 1e9 if ms > 0 else 0.0
+        out = {
+            "metric": "train images/sec (whole node) EffNet-B3+CBAM 300x300 bf16",
+            "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"EfficientNet-B3 {'+ CBAM/MHA head' if use_attention else '(plain head)'}, 4 classes, "
+                                   f"300x300, per-GPU batch {args.batch} (global {world * args.batch}), train step = "
+                                   "fwd + CE + bwd + gradient all-reduce + AdamW; random-init weights, synthetic "
+                                   "MRI-shaped images resident in HBM",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                       "model_tflops_per_s": round(ips * TRAIN_GFLOP_PER_IMG[args.workload] / 1e3, 1)},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "launches_per_step": launches / max(args.steps, 1),
+                         "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2),
+                         "algorithmic_bytes_per_launch": int(nbytes / max(launches, 1))},
+            "final_loss": round(loss_v, 4),
+        }
+        if args.kernel_table:
+            tot = sum(v[1] for v in table.values())
+            for fam, (n, fms, fb) in sorted(table.items(), key=lambda kv: -kv[1][1]):
+                print(f"  {fam:20s} launches {n:4d}  {fms:8.3f} ms  {fb / 1e9:8.2f} GB  "
+                      f"{fb / fms / 1e6 if fms else 0:8.1f} GB/s  {100 * fms / tot:5.1f} %", file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(use_attention=use_attention)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,6 +5,10 @@ import ctypes
 import os
 import re
 
+# torch first: it carries its own HIP runtime, and libmia_hip.so must bind to THAT copy (same streams,
+# same device context). Loading the library before torch would pull in a second runtime.
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, "..", "include", "mia_hip.h")
 LIB_PATH = os.path.join(HERE, "libmia_hip.so")

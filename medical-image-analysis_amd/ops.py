@@ -33,6 +33,40 @@ def part_rows(work_items: int) -> int:
     return max(1, min(MAX_PART, int(work_items)))
 
 
+class KernelTimer:
+    """Optional per-family HIP-event timing of the kernel launches (events are recorded on the stream the
+    kernels are launched on). Off by default; bench.py turns it on for the family it prices against the
+    roofline. `bytes` is the algorithmic HBM traffic of the launch (operands read once, results written once)."""
+    families = None   # None = off, else a set of family names
+    records = {}      # family -> list of (start_event, end_event, bytes)
+
+    @classmethod
+    def start(cls, families):
+        cls.families, cls.records = set(families), {}
+
+    @classmethod
+    def stop(cls):
+        """-> {family: (launches, total_ms, total_bytes)}; synchronises."""
+        torch.cuda.synchronize()
+        out = {}
+        for fam, recs in cls.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            out[fam] = (len(recs), ms, sum(n for _, _, n in recs))
+        cls.families, cls.records = None, {}
+        return out
+
+
+def _launch(family, nbytes, fn, *args):
+    if KernelTimer.families is None or family not in KernelTimer.families:
+        return fn(*args)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    r = fn(*args)
+    b.record()
+    KernelTimer.records.setdefault(family, []).append((a, b, nbytes))
+    return r
+
+
 # ------------------------------------------------------------------------------------------------
 # primitive wrappers
 # ------------------------------------------------------------------------------------------------
@@ -48,7 +82,8 @@ def gemm_nt(a2d, b, out2d=None, *, pscale=None, pshift=None, pro_act=ACT_NONE, g
     part = None
     if stats_rows:
         part = torch.empty((stats_rows, 2, N), dtype=torch.float32, device=a2d.device)
-    lib().mia_gemm_nt(_DT[a2d.dtype], _p(a2d), a2d.stride(0), _p(b), b.stride(0), _p(out2d),
+    esz = a2d.element_size()
+    _launch("gemm_nt", (M * K + N * K + M * N * (2 if add is not None else 1)) * esz, lib().mia_gemm_nt, _DT[a2d.dtype], _p(a2d), a2d.stride(0), _p(b), b.stride(0), _p(out2d),
                       ldc if ldc is not None else out2d.stride(0), _p(add), M, N, K, _p(pscale), _p(pshift), pro_act,
                       _p(gate), rows_per_img, _p(bias), epi_act, _p(part), stats_rows, _stream())
     return out2d, part
@@ -61,7 +96,7 @@ def gemm_tn(g2d, x2d, *, pscale=None, pshift=None, pro_act=ACT_NONE, gate=None, 
     assert x2d.shape[0] == M and g2d.dtype == x2d.dtype
     if out is None:
         out = torch.zeros((N, K), dtype=torch.float32, device=g2d.device)
-    lib().mia_gemm_tn(_DT[g2d.dtype], _p(g2d), g2d.stride(0), _p(x2d), x2d.stride(0), _p(out), out.stride(0), M, N, K,
+    _launch("gemm_tn", (M * N + M * K) * g2d.element_size() + N * K * 4, lib().mia_gemm_tn, _DT[g2d.dtype], _p(g2d), g2d.stride(0), _p(x2d), x2d.stride(0), _p(out), out.stride(0), M, N, K,
                       _p(pscale), _p(pshift), pro_act, _p(gate), rows_per_img, _stream())
     return out
 
@@ -72,7 +107,7 @@ def dwconv_fwd(x, w, k, s, *, pscale=None, pshift=None, stats_rows=0):
     OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
     y = torch.empty((B, OH, OW, C), dtype=x.dtype, device=x.device)
     part = torch.empty((stats_rows, 2, C), dtype=torch.float32, device=x.device) if stats_rows else None
-    lib().mia_dwconv_fwd(_DT[x.dtype], _p(x), B, H, W, C, _p(pscale), _p(pshift), _p(w), k, s, _p(y), _p(part),
+    _launch("dwconv_fwd", (x.numel() + y.numel()) * x.element_size(), lib().mia_dwconv_fwd, _DT[x.dtype], _p(x), B, H, W, C, _p(pscale), _p(pshift), _p(w), k, s, _p(y), _p(part),
                          stats_rows, _stream())
     return y, part
 
@@ -82,7 +117,8 @@ def dwconv_bwd_data(dy, w, k, s, in_hw, *, yfwd=None, escale=None, eshift=None, 
     H, W = in_hw
     dx = torch.empty((B, H, W, C), dtype=dy.dtype, device=dy.device)
     part = torch.empty((stats_rows, 2, C), dtype=torch.float32, device=dy.device) if stats_rows else None
-    lib().mia_dwconv_bwd_data(_DT[dy.dtype], _p(dy), B, H, W, C, _p(w), k, s, _p(dx), _p(yfwd), _p(escale),
+    _launch("dwconv_bwd_data", (dy.numel() + dx.numel() * (2 if yfwd is not None else 1)) * dy.element_size(),
+            lib().mia_dwconv_bwd_data, _DT[dy.dtype], _p(dy), B, H, W, C, _p(w), k, s, _p(dx), _p(yfwd), _p(escale),
                               _p(eshift), _p(emean), _p(erstd), _p(part), stats_rows, _stream())
     return dx, part
 
@@ -90,7 +126,8 @@ def dwconv_bwd_data(dy, w, k, s, in_hw, *, yfwd=None, escale=None, eshift=None, 
 def dwconv_bwd_weight(x, dy, k, s, *, pscale=None, pshift=None):
     B, H, W, C = x.shape
     dw = torch.zeros((C, 1, k, k), dtype=torch.float32, device=x.device)
-    lib().mia_dwconv_bwd_weight(_DT[x.dtype], _p(x), B, H, W, C, _p(pscale), _p(pshift), _p(dy), k, s, _p(dw),
+    _launch("dwconv_bwd_weight", (x.numel() + dy.numel()) * x.element_size(), lib().mia_dwconv_bwd_weight,
+            _DT[x.dtype], _p(x), B, H, W, C, _p(pscale), _p(pshift), _p(dy), k, s, _p(dw),
                                 _stream())
     return dw
 
@@ -132,7 +169,9 @@ def bn_act_bwd_reduce(g, y, stats, act, *, gate=None, dpool=None, rows_per_img=0
     R = g.numel() // C
     rows = part_rows((R + 63) // 64)
     part = torch.empty((rows, 2, C), dtype=torch.float32, device=g.device)
-    lib().mia_bn_act_bwd_reduce(_DT[g.dtype], _p(g), _p(y), R, C, _p(stats[0]), _p(stats[1]), _p(stats[2]),
+    writes = act != ACT_NONE or gate is not None or dpool is not None
+    _launch("bn_act_bwd_reduce", g.numel() * g.element_size() * (3 if writes else 2), lib().mia_bn_act_bwd_reduce,
+            _DT[g.dtype], _p(g), _p(y), R, C, _p(stats[0]), _p(stats[1]), _p(stats[2]),
                                 _p(stats[3]), act, _p(gate), _p(dpool), rows_per_img, _p(part), rows, _stream())
     return part
 
@@ -142,7 +181,8 @@ def affine2(x, a, d, *, y=None, b=None, res=None, act=ACT_NONE, out=None):
     R = x.numel() // C
     if out is None:
         out = torch.empty_like(x)
-    lib().mia_affine2(_DT[x.dtype], _p(x), _p(y), _p(res), _p(out), R, C, _p(a), _p(b), _p(d), act, _stream())
+    _launch("affine2", x.numel() * x.element_size() * (2 + (y is not None) + (res is not None)), lib().mia_affine2,
+            _DT[x.dtype], _p(x), _p(y), _p(res), _p(out), R, C, _p(a), _p(b), _p(d), act, _stream())
     return out
 
 
@@ -151,7 +191,8 @@ def img_colsum(y, wt, scale, shift, act):
     HW = H * W
     splits = max(1, min(16, HW // 1024))
     out = torch.empty((B, splits, C), dtype=torch.float32, device=y.device)
-    lib().mia_img_colsum(_DT[y.dtype], _p(y), _p(wt), B, HW, C, _p(scale), _p(shift), act, splits, _p(out), _stream())
+    _launch("img_colsum", y.numel() * y.element_size() * (2 if wt is not None else 1), lib().mia_img_colsum,
+            _DT[y.dtype], _p(y), _p(wt), B, HW, C, _p(scale), _p(shift), act, splits, _p(out), _stream())
     return out
 
 

@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import mia_amd  # noqa: E402,F401
-from mia_amd.src.model import create_foundation_model, load_model_weights_safely  # noqa: E402
+from mia_amd.src.model import FoundationModel, create_foundation_model, load_model_weights_safely  # noqa: E402
 from mia_amd.trunk import EfficientNetB3Features, MBConv  # noqa: E402
 from oracle import effnet_b3 as O  # noqa: E402
 from seeding import randn, seeded_state_dict  # noqa: E402
@@ -91,8 +91,10 @@ def _pair(use_attention, seed=3):
     ref = O.OracleFoundationModel(heads, dropout=0.0, use_attention=use_attention)
     sd = seeded_state_dict(ref, seed)
     ref.load_state_dict(sd)
-    mine = create_foundation_model(backbone="efficientnet_b3", pretrained=False, dropout=0.0,
-                                   classification_heads=heads, use_attention=use_attention)
+    # FoundationModel directly: the factory's keyword form turns dropout=0.0 into 0.2 (`dropout or 0.2`,
+    # reference model.py:539), which this build reproduces.
+    mine = FoundationModel(backbone="efficientnet_b3", pretrained=False, dropout=0.0,
+                           classification_heads=heads, use_attention=use_attention)
     missing, unexpected = load_model_weights_safely(mine, {"model_state_dict": sd})
     assert not missing and not unexpected
     return ref, mine.cuda()
@@ -115,11 +117,23 @@ def test_c1_step_fp32_batch8_300px(use_attention):
     print("logit relerr", e)
     assert e < 1e-4
     pr = dict(ref.named_parameters())
-    worst = (0.0, "")
+    rows = []
     for n, p in mine.named_parameters():
         assert p.grad is not None, n
-        ge = relerr(p.grad, pr[n].grad)
-        worst = max(worst, (ge, n))
+        a, b = p.grad.detach().double().cpu(), pr[n].grad.detach().double()
+        rows.append(((a - b).abs().max().item(), b.abs().max().item(), n))
+    # A BatchNorm bias whose every consumer is conv -> train-mode BatchNorm (all bn3.bias / ds bn2.bias below the
+    # last stage) has an exactly-zero true gradient: per-channel shifts are removed by the next normalisation.
+    # Both sides then hold rounding noise, so those entries are compared against the gradient scale of their own
+    # layer's weight (bn3.weight) rather than against noise.
+    scale = {n: m for _, m, n in rows}
+    worst = (0.0, "")
+    for err, mag, n in rows:
+        if n.endswith(".bias") and ".bn" in n and "backbone" in n:
+            mag = max(mag, scale[n[:-4] + "weight"])
+        worst = max(worst, (err / max(mag, 1e-30), n))
+    for err, mag, n in sorted(rows, key=lambda r: -r[0] / max(r[1], 1e-30))[:8]:
+        print(f"  {n:50s} abs err {err:.3e}  ref max {mag:.3e}")
     print("worst grad relerr", worst)
     assert worst[0] < 1e-3, worst
 
