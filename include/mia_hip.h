@@ -92,6 +92,56 @@ int mia_se_gate_bwd(const float* dgate_part, int B, int splits, int HW, int C, i
                     const float* We, const float* gate, const float* hpre, const float* pooled, float* dpre2,
                     float* dpre1, float* dpool, float* dWr, float* dbr, float* dWe, float* dbe, void* stream);
 
+/* ---- CBAM (src/model.py:28-108) on an NHWC feature map x [B,H*W,C] -----------------------------------------
+ * channel gate (ChannelGate, model.py:45-67): avg/max pool over H*W, shared MLP C->HID->C (ReLU) on both, sum,
+ * sigmoid -> cscale [B,C]. avg, mx, amax (arg-max pixel), ha, hm (hidden activations) are kept for the backward. */
+int mia_cbam_channel_fwd(int dtype, const void* x, int B, int HW, int C, int HID, const float* W1, const float* b1,
+                         const float* W2, const float* b2, float* avg, float* mx, int* amax, float* ha, float* hm,
+                         float* cscale, void* stream);
+/* spatial gate, first half (ChannelPool + 7x7 conv, model.py:77-91): comp [B,HW,2] = (max_c, mean_c) of x*cscale,
+ * cmax = arg-max channel, pre = conv7x7(comp) (w7 [2][7][7]); part [part_rows][2][1] feeds mia_bn_finalize_fwd (C=1). */
+int mia_cbam_spatial_fwd(int dtype, const void* x, const float* cscale, int B, int H, int W, int C, const float* w7,
+                         float* comp, int* cmax, float* pre, float* part, int part_rows, void* stream);
+/* out = x * cscale[b,c] * sigmoid(pre*bnst[0] + bnst[1])[b,p]  (model.py:66-67, :92-93); sgate [B,HW] stored. */
+int mia_cbam_apply(int dtype, const void* x, const float* cscale, const float* pre, const float* bnst, int B, int HW,
+                   int C, void* out, float* sgate, void* stream);
+/* Backward of the whole CBAM module. bnst = {scale, shift, mean, rstd} of the BatchNorm(1); ws: fp32 scratch of
+ * 4*B*H*W + 4*B*C + 2*B*HID floats. */
+int mia_cbam_bwd(int dtype, const void* dx2, const void* x, int B, int H, int W, int C, int HID, const float* cscale,
+                 const float* sgate, const float* pre, const float* bnst, const float* bn_gamma, int bn_training,
+                 const float* comp, const int* cmax, const int* amax, const float* avg, const float* mx,
+                 const float* ha, const float* hm, const float* W1, const float* W2, const float* w7, float* ws,
+                 void* dx, float* dW1, float* db1, float* dW2, float* db2, float* dw7, float* dbn_gamma,
+                 float* dbn_beta, void* stream);
+
+/* ---- multi-head self-attention core (MultiHeadAttentionClassifier.forward, model.py:153-163) --------------------
+ * qkv [B*HW, 3C] (query | key | value projections, head h = columns h*HD..) -> out [B*HW, C];
+ * softmax(QK^T/sqrt(HD)) is written to P [B,heads,HW,HW] (fp32) for the backward; dropout(pdrop) on the weights
+ * uses a counter-based mask from `seed` that the backward regenerates. HW <= 256, HD in {8,16,32,48,64}. */
+int mia_attention_fwd(int dtype, const void* qkv, int B, int HW, int C, int heads, float pdrop,
+                      unsigned long long seed, float* P, void* out, void* stream);
+int mia_attention_bwd(int dtype, const void* qkv, const float* P, const void* dout, int B, int HW, int C, int heads,
+                      float pdrop, unsigned long long seed, void* dqkv, void* stream);
+
+/* ---- classifier front end: AdaptiveAvgPool2d(1) -> Flatten -> [LayerNorm] -> Dropout (model.py:134-137, :309-311)
+ * in_part [B][S][C]: per-image channel sums over H*W (mia_img_colsum). gamma/beta NULL = no LayerNorm. */
+int mia_pool_ln_dropout_fwd(const float* in_part, int B, int S, int HW, int C, const float* gamma, const float* beta,
+                            float eps, float pdrop, unsigned long long seed, float* out, float* xhat, float* rstd,
+                            void* stream);
+int mia_pool_ln_dropout_bwd(const float* dout, int B, int C, const float* gamma, const float* xhat, const float* rstd,
+                            float pdrop, unsigned long long seed, float* dpooled, float* dgamma_rows,
+                            float* dbeta_rows, void* stream);
+/* out[b,p,c] = v[b,c]*mult (+ res[b,p,c]): gradient of the average pool spread back over H*W. */
+int mia_broadcast_rows(int dtype, const float* v, int B, int HW, int C, float mult, const void* res, void* out,
+                       void* stream);
+/* x *= dropout mask (and zero where relu_ref <= 0): nn.Dropout after nn.ReLU, forward and backward. */
+int mia_dropout_f32(float* x, const float* relu_ref, long long n, float pdrop, unsigned long long seed, void* stream);
+/* out[c] = sum_r x[r][c]: bias gradients. */
+int mia_colsum(int dtype, const void* x, long long R, int C, int ld, float* out, void* stream);
+/* nn.CrossEntropyLoss (src/loss.py:147; train.py:352): mean loss and d loss / d logits (zero padded to ldd columns). */
+int mia_softmax_ce(const float* logits, int ld, const long long* labels, int B, int n, float* loss, float* dlogits,
+                   int ldd, void* stream);
+
 /* ---- stem: timm conv_stem (3->40, k3 s2 p1) as im2col + mia_gemm_nt. x is NCHW fp32 (the tensor the
  *      reference feeds the model, train.py:345-351); col is [B*OH*OW][32], columns 27..31 zero. */
 int mia_stem_im2col(int dtype, const float* x, int B, int H, int W, void* col, void* stream);

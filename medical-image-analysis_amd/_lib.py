@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(HERE, "libmia_hip.so")
 _CTYPES = {
     "int": ctypes.c_int,
     "long long": ctypes.c_longlong,
+    "unsigned long long": ctypes.c_ulonglong,
     "float": ctypes.c_float,
     "double": ctypes.c_double,
 }

@@ -1,0 +1,881 @@
+// Classification-head kernels (gfx950): CBAM channel + spatial attention, multi-head self-attention core,
+// LayerNorm/dropout, cross-entropy. The feature map is NHWC [B, HW, C] in the compute dtype T; everything
+// internal is fp32. The four Linear layers of the attention head and the MLP run on the MFMA GEMMs of gemm.hip.
+//
+// Reductions use wavefront shuffles (DPP) for per-pixel channel pooling and LDS for per-image pooling.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// counter-based dropout mask: keep iff hash(seed, idx) >= p.  Recomputed, never stored.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned long long idx, float p) {
+    if (p <= 0.f) return 1.f;
+    unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+    return u >= p ? 1.0f / (1.0f - p) : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CBAM channel gate: per-image average and max over H*W (with the arg-max pixel for the backward pass)
+// grid (B, ceil(C/256)), one thread per channel, rows streamed with channel-contiguous (coalesced) loads
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cbam_channel_pool_kernel(const T* x, int HW, int C, float* avg, float* mx,
+                                                                int* amax) {
+    const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const T* p = x + (size_t)b * HW * C + c;
+    float s = 0.f, m = -INFINITY;
+    int am = 0;
+    for (int r = 0; r < HW; ++r) {
+        const float v = to_f32<T>(p[(size_t)r * C]);
+        s += v;
+        if (v > m) { m = v; am = r; }
+    }
+    avg[(size_t)b * C + c] = s / (float)HW;
+    mx[(size_t)b * C + c] = m;
+    amax[(size_t)b * C + c] = am;
+}
+
+// shared MLP C -> HID -> C on both pooled vectors, summed, sigmoid. One workgroup per image.
+__global__ __launch_bounds__(256) void cbam_channel_mlp_kernel(const float* avg, const float* mx, int C, int HID,
+                                                               const float* W1, const float* b1, const float* W2,
+                                                               const float* b2, float* ha, float* hm, float* cscale) {
+    extern __shared__ float sm[];
+    float* sa = sm;           // [C]
+    float* sx = sm + C;       // [C]
+    float* hs = sm + 2 * C;   // [HID] (ha + hm)
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < C; c += 256) {
+        sa[c] = avg[(size_t)b * C + c];
+        sx[c] = mx[(size_t)b * C + c];
+    }
+    __syncthreads();
+    for (int j = wave; j < HID; j += 4) {
+        float da = 0.f, dm = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float w = W1[(size_t)j * C + c];
+            da += w * sa[c];
+            dm += w * sx[c];
+        }
+        da = wave_sum(da);
+        dm = wave_sum(dm);
+        if (lane == 0) {
+            const float a = fmaxf(da + b1[j], 0.f), m = fmaxf(dm + b1[j], 0.f);
+            ha[(size_t)b * HID + j] = a;
+            hm[(size_t)b * HID + j] = m;
+            hs[j] = a + m;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float d = 2.f * b2[c];
+        for (int j = 0; j < HID; ++j) d += W2[(size_t)c * HID + j] * hs[j];
+        cscale[(size_t)b * C + c] = sigmoidf_(d);
+    }
+}
+
+// channel pool of x*cscale per pixel: comp[b][p] = (max_c, mean_c), arg-max channel kept. One wave per pixel.
+template <typename T>
+__global__ __launch_bounds__(256) void cbam_spatial_pool_kernel(const T* x, const float* cscale, int B, int HW, int C,
+                                                                float* comp, int* cmax) {
+    const int lane = threadIdx.x & 63;
+    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= (long long)B * HW) return;
+    const int b = (int)(pix / HW);
+    const T* p = x + (size_t)pix * C;
+    const float* cs = cscale + (size_t)b * C;
+    float s = 0.f, m = -INFINITY;
+    int am = 0;
+    for (int c = lane; c < C; c += 64) {
+        const float v = to_f32<T>(p[c]) * cs[c];
+        s += v;
+        if (v > m) { m = v; am = c; }
+    }
+    s = wave_sum(s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64);
+        const int oa = __shfl_xor(am, o, 64);
+        if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+    }
+    if (lane == 0) {
+        comp[(size_t)pix * 2 + 0] = m;
+        comp[(size_t)pix * 2 + 1] = s / (float)C;
+        cmax[pix] = am;
+    }
+}
+
+// 7x7 conv (2 -> 1, pad 3, no bias) over comp [B,H,W,2]; partial sums of pre and pre^2 for BatchNorm(1)
+__global__ __launch_bounds__(256) void cbam_spatial_conv_kernel(const float* comp, int B, int H, int W, const float* w7,
+                                                                float* pre, float* part) {
+    __shared__ float ws[98];
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x;
+    if (tid < 98) ws[tid] = w7[tid];  // [ch][kh][kw], ch 0 = max, 1 = mean
+    __syncthreads();
+    const long long total = (long long)B * H * W;
+    float s = 0.f, q = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < total; i += (long long)gridDim.x * 256) {
+        const int xw = (int)(i % W), yh = (int)((i / W) % H);
+        const long long b = i / ((long long)W * H);
+        float acc = 0.f;
+        for (int kh = 0; kh < 7; ++kh) {
+            const int ih = yh + kh - 3;
+            if (ih < 0 || ih >= H) continue;
+            for (int kw = 0; kw < 7; ++kw) {
+                const int iw = xw + kw - 3;
+                if (iw < 0 || iw >= W) continue;
+                const float* cp = comp + ((size_t)(b * H + ih) * W + iw) * 2;
+                acc += cp[0] * ws[kh * 7 + kw] + cp[1] * ws[49 + kh * 7 + kw];
+            }
+        }
+        pre[i] = acc;
+        s += acc;
+        q += acc * acc;
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        part[(size_t)blockIdx.x * 2 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        part[(size_t)blockIdx.x * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+// x2 = x * cscale[b,c] * sigmoid(pre*s + t)[b,p]; also stores the spatial gate
+template <typename T>
+__global__ __launch_bounds__(256) void cbam_apply_kernel(const T* x, const float* cscale, const float* pre,
+                                                         const float* bnst, int B, int HW, int C, T* out, float* sgate) {
+    const long long nvec = (long long)B * HW * C / 4;
+    const float s = bnst[0], t = bnst[1];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const size_t idx = (size_t)i * 4;
+        const long long pix = idx / C;
+        const int c = (int)(idx % C), b = (int)(pix / HW);
+        const float g = sigmoidf_(pre[pix] * s + t);
+        if (c == 0) sgate[pix] = g;
+        const f4 v = load4<T>(x + idx), cs = load4<float>(cscale + (size_t)b * C + c);
+        store4<T>(out + idx, f4{v.x * cs.x * g, v.y * cs.y * g, v.z * cs.z * g, v.w * cs.w * g});
+    }
+}
+
+// ---- CBAM backward ----
+// dsg[b,p] = sum_c dx2 * x * cscale. One wave per pixel.
+template <typename T>
+__global__ __launch_bounds__(256) void cbam_bwd_dsgate_kernel(const T* dx2, const T* x, const float* cscale, int B,
+                                                              int HW, int C, float* dsg) {
+    const int lane = threadIdx.x & 63;
+    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= (long long)B * HW) return;
+    const int b = (int)(pix / HW);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64)
+        s += to_f32<T>(dx2[(size_t)pix * C + c]) * to_f32<T>(x[(size_t)pix * C + c]) * cscale[(size_t)b * C + c];
+    s = wave_sum(s);
+    if (lane == 0) dsg[pix] = s;
+}
+
+// BatchNorm(1)+sigmoid backward over all N = B*HW values. One workgroup (N is small: 12,800 at batch 128).
+// in: dsg, sgate, pre, st = {scale, shift, mean, rstd}, gamma. out: dpre (gradient of the conv output), dgamma, dbeta
+__global__ __launch_bounds__(1024) void cbam_bwd_spatial_bn_kernel(const float* dsg, const float* sgate,
+                                                                   const float* pre, const float* st,
+                                                                   const float* gamma, int training, long long N,
+                                                                   float* dpre, float* dgamma, float* dbeta) {
+    __shared__ float red[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float mean = st[2], rstd = st[3];
+    float s = 0.f, q = 0.f;
+    for (long long i = tid; i < N; i += 1024) {
+        const float sg = sgate[i];
+        const float g = dsg[i] * sg * (1.f - sg);
+        s += g;
+        q += g * ((pre[i] - mean) * rstd);
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = q; }
+    __syncthreads();
+    float S = 0.f, Q = 0.f;
+    for (int k = 0; k < 16; ++k) { S += red[0][k]; Q += red[1][k]; }
+    const float ga = gamma[0];
+    const float invn = 1.0f / (float)N;
+    for (long long i = tid; i < N; i += 1024) {
+        const float sg = sgate[i];
+        const float g = dsg[i] * sg * (1.f - sg);
+        const float xh = (pre[i] - mean) * rstd;
+        dpre[i] = training ? ga * rstd * (g - S * invn - xh * Q * invn) : ga * rstd * g;
+    }
+    if (tid == 0) { dgamma[0] = Q; dbeta[0] = S; }
+}
+
+// weight gradient of the 7x7 conv: dw[ch][kh][kw] = sum_{b,y,x} dpre[b,y,x] * comp[b,y+kh-3,x+kw-3,ch]. grid = 98.
+__global__ __launch_bounds__(256) void cbam_bwd_conv_weight_kernel(const float* dpre, const float* comp, int B, int H,
+                                                                   int W, float* dw7) {
+    __shared__ float red[4];
+    const int tap = blockIdx.x, ch = tap / 49, kh = (tap % 49) / 7, kw = tap % 7;
+    const long long total = (long long)B * H * W;
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < total; i += 256) {
+        const int xw = (int)(i % W), yh = (int)((i / W) % H);
+        const long long b = i / ((long long)W * H);
+        const int ih = yh + kh - 3, iw = xw + kw - 3;
+        if (ih >= 0 && ih < H && iw >= 0 && iw < W) s += dpre[i] * comp[((size_t)(b * H + ih) * W + iw) * 2 + ch];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) dw7[tap] = red[0] + red[1] + red[2] + red[3];
+}
+
+// dcomp[b,p,ch] = sum_taps dpre[b, p - tap] * w[ch][tap]  (data gradient of the 7x7 conv)
+__global__ __launch_bounds__(256) void cbam_bwd_conv_data_kernel(const float* dpre, int B, int H, int W, const float* w7,
+                                                                 float* dcomp) {
+    __shared__ float ws[98];
+    if (threadIdx.x < 98) ws[threadIdx.x] = w7[threadIdx.x];
+    __syncthreads();
+    const long long total = (long long)B * H * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int xw = (int)(i % W), yh = (int)((i / W) % H);
+        const long long b = i / ((long long)W * H);
+        float a0 = 0.f, a1 = 0.f;
+        for (int kh = 0; kh < 7; ++kh) {
+            const int oh = yh - kh + 3;
+            if (oh < 0 || oh >= H) continue;
+            for (int kw = 0; kw < 7; ++kw) {
+                const int ow = xw - kw + 3;
+                if (ow < 0 || ow >= W) continue;
+                const float g = dpre[(size_t)(b * H + oh) * W + ow];
+                a0 += g * ws[kh * 7 + kw];
+                a1 += g * ws[49 + kh * 7 + kw];
+            }
+        }
+        dcomp[(size_t)i * 2 + 0] = a0;
+        dcomp[(size_t)i * 2 + 1] = a1;
+    }
+}
+
+// pass 1 of the input gradient: dx1 = dx2*sg + dcomp_mean/C + dcomp_max*[c == cmax]; dcs[b,c] = sum_p dx1 * x.
+// grid (B, ceil(C/256)), one thread per channel.
+template <typename T>
+__global__ __launch_bounds__(256) void cbam_bwd_dcs_kernel(const T* dx2, const T* x, const float* sgate,
+                                                           const float* dcomp, const int* cmax, int HW, int C,
+                                                           float* dcs) {
+    const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    const float invc = 1.0f / (float)C;
+    for (int r = 0; r < HW; ++r) {
+        const size_t pix = (size_t)b * HW + r;
+        float d = to_f32<T>(dx2[pix * C + c]) * sgate[pix] + dcomp[pix * 2 + 1] * invc;
+        if (cmax[pix] == c) d += dcomp[pix * 2 + 0];
+        s += d * to_f32<T>(x[pix * C + c]);
+    }
+    dcs[(size_t)b * C + c] = s;
+}
+
+// channel-MLP backward for one image: datt, dpre_a, dpre_m kept for the parameter gradients; davg, dmax out
+__global__ __launch_bounds__(256) void cbam_bwd_mlp_kernel(const float* dcs, const float* cscale, const float* ha,
+                                                           const float* hm, int C, int HID, const float* W1,
+                                                           const float* W2, float* datt, float* dpa, float* dpm,
+                                                           float* davg, float* dmax) {
+    extern __shared__ float sm[];
+    float* da = sm;            // [C]
+    float* pa = sm + C;        // [HID]
+    float* pm = pa + HID;      // [HID]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < C; c += 256) {
+        const float cs = cscale[(size_t)b * C + c];
+        const float v = dcs[(size_t)b * C + c] * cs * (1.f - cs);
+        da[c] = v;
+        datt[(size_t)b * C + c] = v;
+    }
+    __syncthreads();
+    for (int j = wave; j < HID; j += 4) {
+        float d = 0.f;
+        for (int c = lane; c < C; c += 64) d += W2[(size_t)c * HID + j] * da[c];
+        d = wave_sum(d);
+        if (lane == 0) {
+            const float a = ha[(size_t)b * HID + j] > 0.f ? d : 0.f;
+            const float m = hm[(size_t)b * HID + j] > 0.f ? d : 0.f;
+            pa[j] = a; pm[j] = m;
+            dpa[(size_t)b * HID + j] = a;
+            dpm[(size_t)b * HID + j] = m;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float a = 0.f, m = 0.f;
+        for (int j = 0; j < HID; ++j) {
+            const float w = W1[(size_t)j * C + c];
+            a += w * pa[j];
+            m += w * pm[j];
+        }
+        davg[(size_t)b * C + c] = a;
+        dmax[(size_t)b * C + c] = m;
+    }
+}
+
+// parameter gradients of the channel MLP summed over the batch; thread per (c, j)
+__global__ __launch_bounds__(256) void cbam_bwd_mlp_param_kernel(int B, int C, int HID, const float* datt,
+                                                                 const float* dpa, const float* dpm, const float* ha,
+                                                                 const float* hm, const float* avg, const float* mx,
+                                                                 float* dW1, float* db1, float* dW2, float* db2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= C * HID) return;
+    const int c = i / HID, j = i % HID;
+    float w2 = 0.f, w1 = 0.f, bb2 = 0.f, bb1 = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float d = datt[(size_t)b * C + c];
+        const float a = dpa[(size_t)b * HID + j], m = dpm[(size_t)b * HID + j];
+        w2 += d * (ha[(size_t)b * HID + j] + hm[(size_t)b * HID + j]);
+        w1 += a * avg[(size_t)b * C + c] + m * mx[(size_t)b * C + c];
+        bb2 += 2.f * d;
+        bb1 += a + m;
+    }
+    dW2[(size_t)c * HID + j] = w2;
+    dW1[(size_t)j * C + c] = w1;
+    if (j == 0) db2[c] = bb2;
+    if (c == 0) db1[j] = bb1;
+}
+
+// pass 2: dx = dx1 * cscale + davg/HW + dmax*[p == amax]
+template <typename T>
+__global__ __launch_bounds__(256) void cbam_bwd_dx_kernel(const T* dx2, const float* sgate, const float* dcomp,
+                                                          const int* cmax, const float* cscale, const float* davg,
+                                                          const float* dmax, const int* amax, int B, int HW, int C,
+                                                          T* dx) {
+    const long long n = (long long)B * HW * C;
+    const float invc = 1.0f / (float)C, invhw = 1.0f / (float)HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long pix = i / C;
+        const int c = (int)(i % C), b = (int)(pix / HW), r = (int)(pix % HW);
+        float d = to_f32<T>(dx2[i]) * sgate[pix] + dcomp[pix * 2 + 1] * invc;
+        if (cmax[pix] == c) d += dcomp[pix * 2 + 0];
+        const size_t bc = (size_t)b * C + c;
+        float o = d * cscale[bc] + davg[bc] * invhw;
+        if (amax[bc] == r) o += dmax[bc];
+        dx[i] = from_f32<T>(o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-head self-attention core on qkv [B*HW, 3C] (q | k | v, each head a contiguous HD slice)
+// one workgroup per (image, head); K and V rows live in LDS and are read as broadcasts
+// ------------------------------------------------------------------------------------------------
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attention_fwd_kernel(const T* qkv, int HW, int C, int heads, float scale,
+                                                            float pdrop, unsigned long long seed, float* P, T* out) {
+    extern __shared__ float sm[];
+    float* Ks = sm;             // [HW][HD]
+    float* Vs = sm + HW * HD;   // [HW][HD]
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const size_t row0 = (size_t)b * HW;
+    const int ld = 3 * C;
+    for (int i = threadIdx.x; i < HW * HD; i += 256) {
+        const int r = i / HD, d = i % HD;
+        Ks[i] = to_f32<T>(qkv[(row0 + r) * ld + C + h * HD + d]);
+        Vs[i] = to_f32<T>(qkv[(row0 + r) * ld + 2 * C + h * HD + d]);
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < HW; r += 256) {
+        float q[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) q[d] = to_f32<T>(qkv[(row0 + r) * ld + h * HD + d]) * scale;
+        float m = -INFINITY, l = 0.f;
+        for (int j = 0; j < HW; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) s += q[d] * Ks[j * HD + d];
+            const float mn = fmaxf(m, s);
+            l = l * __expf(m - mn) + __expf(s - mn);
+            m = mn;
+        }
+        const float invl = 1.0f / l;
+        float o[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) o[d] = 0.f;
+        float* prow = P + (((size_t)b * heads + h) * HW + r) * HW;
+        for (int j = 0; j < HW; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) s += q[d] * Ks[j * HD + d];
+            const float p = __expf(s - m) * invl;
+            prow[j] = p;
+            const float pd = p * drop_scale(seed, (((unsigned long long)b * heads + h) * HW + r) * HW + j, pdrop);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) o[d] += pd * Vs[j * HD + d];
+        }
+#pragma unroll
+        for (int d = 0; d < HD; ++d) out[(row0 + r) * C + h * HD + d] = from_f32<T>(o[d]);
+    }
+}
+
+// backward: dqkv from dO, P and qkv. Phase A (thread = query row): D_r and dQ; phase B (thread = key row): dK, dV.
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const T* qkv, const float* P, const T* dout, int HW, int C,
+                                                            int heads, float scale, float pdrop,
+                                                            unsigned long long seed, T* dqkv) {
+    extern __shared__ float sm[];
+    float* As = sm;             // phase A: K ; phase B: Q
+    float* Bs = sm + HW * HD;   // phase A: V ; phase B: dO
+    float* Dr = sm + 2 * HW * HD;  // [HW]
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const size_t row0 = (size_t)b * HW;
+    const int ld = 3 * C;
+    const unsigned long long pbase = ((unsigned long long)b * heads + h) * HW;
+    for (int i = threadIdx.x; i < HW * HD; i += 256) {
+        const int r = i / HD, d = i % HD;
+        As[i] = to_f32<T>(qkv[(row0 + r) * ld + C + h * HD + d]);
+        Bs[i] = to_f32<T>(qkv[(row0 + r) * ld + 2 * C + h * HD + d]);
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < HW; r += 256) {
+        float g[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) g[d] = to_f32<T>(dout[(row0 + r) * C + h * HD + d]);
+        const float* prow = P + (pbase + r) * HW;
+        float D = 0.f;
+        for (int j = 0; j < HW; ++j) {
+            float dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) dp += g[d] * Bs[j * HD + d];
+            dp *= drop_scale(seed, (pbase + r) * HW + j, pdrop);
+            D += prow[j] * dp;
+        }
+        Dr[r] = D;
+        float dq[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) dq[d] = 0.f;
+        for (int j = 0; j < HW; ++j) {
+            float dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) dp += g[d] * Bs[j * HD + d];
+            dp *= drop_scale(seed, (pbase + r) * HW + j, pdrop);
+            const float ds = prow[j] * (dp - D) * scale;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) dq[d] += ds * As[j * HD + d];
+        }
+#pragma unroll
+        for (int d = 0; d < HD; ++d) dqkv[(row0 + r) * ld + h * HD + d] = from_f32<T>(dq[d]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HW * HD; i += 256) {
+        const int r = i / HD, d = i % HD;
+        As[i] = to_f32<T>(qkv[(row0 + r) * ld + h * HD + d]);      // Q
+        Bs[i] = to_f32<T>(dout[(row0 + r) * C + h * HD + d]);      // dO
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < HW; j += 256) {
+        float vj[HD], dk[HD], dv[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            vj[d] = to_f32<T>(qkv[(row0 + j) * ld + 2 * C + h * HD + d]);
+            dk[d] = 0.f;
+            dv[d] = 0.f;
+        }
+        for (int r = 0; r < HW; ++r) {
+            const float p = P[(pbase + r) * HW + j];
+            const float dsc = drop_scale(seed, (pbase + r) * HW + j, pdrop);
+            float dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) dp += Bs[r * HD + d] * vj[d];
+            dp *= dsc;
+            const float ds = p * (dp - Dr[r]) * scale;
+            const float pd = p * dsc;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                dk[d] += ds * As[r * HD + d];
+                dv[d] += pd * Bs[r * HD + d];
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            dqkv[(row0 + j) * ld + C + h * HD + d] = from_f32<T>(dk[d]);
+            dqkv[(row0 + j) * ld + 2 * C + h * HD + d] = from_f32<T>(dv[d]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pooled features -> (LayerNorm) -> dropout. One wave per image row. in_part [B][S][C] holds sums over H*W.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_ln_dropout_fwd_kernel(const float* in_part, int B, int S, int C,
+                                                                  float inv_hw, const float* gamma, const float* beta,
+                                                                  float eps, float pdrop, unsigned long long seed,
+                                                                  float* out, float* xhat, float* rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float s = 0.f, q = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        float v = 0.f;
+        for (int k = 0; k < S; ++k) v += in_part[((size_t)b * S + k) * C + c];
+        v *= inv_hw;
+        xhat[(size_t)b * C + c] = v;  // pooled value for now
+        s += v;
+    }
+    s = wave_sum(s);
+    const float mean = s / (float)C;
+    float rs = 1.f;
+    if (gamma) {
+        for (int c = lane; c < C; c += 64) {
+            const float d = xhat[(size_t)b * C + c] - mean;
+            q += d * d;
+        }
+        q = wave_sum(q);
+        rs = 1.0f / sqrtf(q / (float)C + eps);
+    }
+    for (int c = lane; c < C; c += 64) {
+        float v = xhat[(size_t)b * C + c];
+        if (gamma) {
+            const float xh = (v - mean) * rs;
+            xhat[(size_t)b * C + c] = xh;
+            v = xh * gamma[c] + beta[c];
+        }
+        out[(size_t)b * C + c] = v * drop_scale(seed, (unsigned long long)b * C + c, pdrop);
+    }
+    if (lane == 0) rstd_out[b] = rs;
+}
+
+// backward: dpooled [B,C] from dout [B,C]; per-image partial dgamma/dbeta rows are summed by a colsum afterwards
+__global__ __launch_bounds__(256) void pool_ln_dropout_bwd_kernel(const float* dout, int B, int C, const float* gamma,
+                                                                  const float* xhat, const float* rstd, float pdrop,
+                                                                  unsigned long long seed, float* dpooled,
+                                                                  float* dgamma_rows, float* dbeta_rows) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    if (!gamma) {
+        for (int c = lane; c < C; c += 64)
+            dpooled[(size_t)b * C + c] = dout[(size_t)b * C + c] * drop_scale(seed, (unsigned long long)b * C + c, pdrop);
+        return;
+    }
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float dy = dout[(size_t)b * C + c] * drop_scale(seed, (unsigned long long)b * C + c, pdrop);
+        const float xh = xhat[(size_t)b * C + c];
+        dgamma_rows[(size_t)b * C + c] = dy * xh;
+        dbeta_rows[(size_t)b * C + c] = dy;
+        const float dxh = dy * gamma[c];
+        s1 += dxh;
+        s2 += dxh * xh;
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+    const float rs = rstd[b];
+    for (int c = lane; c < C; c += 64) {
+        const float dy = dout[(size_t)b * C + c] * drop_scale(seed, (unsigned long long)b * C + c, pdrop);
+        const float xh = xhat[(size_t)b * C + c];
+        dpooled[(size_t)b * C + c] = rs * (dy * gamma[c] - s1 - xh * s2);
+    }
+}
+
+// out[b, p, c] = v[b, c] * mult (+ res): gradient of the average pool broadcast back over H*W
+template <typename T>
+__global__ __launch_bounds__(256) void broadcast_rows_kernel(const float* v, int B, int HW, int C, float mult,
+                                                             const T* res, T* out) {
+    const long long nvec = (long long)B * HW * C / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const size_t idx = (size_t)i * 4;
+        const int c = (int)(idx % C), b = (int)(idx / ((size_t)HW * C));
+        f4 a = load4<float>(v + (size_t)b * C + c);
+        a.x *= mult; a.y *= mult; a.z *= mult; a.w *= mult;
+        if (res) {
+            const f4 r = load4<T>(res + idx);
+            a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+        }
+        store4<T>(out + idx, a);
+    }
+}
+
+// y = x * dropout_mask (in place), optionally gated by (ref > 0): dropout forward, or ReLU+dropout backward
+__global__ __launch_bounds__(256) void dropout_f32_kernel(float* x, const float* relu_ref, long long n, float pdrop,
+                                                          unsigned long long seed) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float v = x[i] * drop_scale(seed, (unsigned long long)i, pdrop);
+        if (relu_ref && !(relu_ref[i] > 0.f)) v = 0.f;
+        x[i] = v;
+    }
+}
+
+// column sums of an fp32 [R, C] matrix (bias gradients). grid = ceil(C/64); fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, long long R, int C, int ld, float* out) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C)
+        for (long long r = w; r < R; r += 4) s += to_f32<T>(x[(size_t)r * ld + c]);
+    red[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < C) out[c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// softmax cross-entropy, mean over the batch, with its gradient (d loss / d logits). One workgroup.
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* logits, const long long* labels, int B, int n,
+                                                         int ld, float* loss, float* dlogits, int ldd) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* z = logits + (size_t)b * ld;
+        float m = -INFINITY;
+        for (int j = 0; j < n; ++j) m = fmaxf(m, z[j]);
+        float l = 0.f;
+        for (int j = 0; j < n; ++j) l += expf(z[j] - m);
+        const float lse = m + logf(l);
+        const int y = (int)labels[b];
+        acc += lse - z[y];
+        for (int j = 0; j < ldd; ++j)
+            dlogits[(size_t)b * ldd + j] = j < n ? (expf(z[j] - lse) - (j == y ? 1.f : 0.f)) / (float)B : 0.f;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+}
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+#define MIA_STREAM reinterpret_cast<hipStream_t>(stream)
+static inline unsigned grid1d(long long n, int per = 256, long long cap = 16384) {
+    long long b = (n + per - 1) / per;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+extern "C" int mia_cbam_channel_fwd(int dtype, const void* x, int B, int HW, int C, int HID, const float* W1,
+                                    const float* b1, const float* W2, const float* b2, float* avg, float* mx,
+                                    int* amax, float* ha, float* hm, float* cscale, void* stream) {
+    MIA_CHECK_ARG(x && W1 && b1 && W2 && b2 && avg && mx && amax && ha && hm && cscale, "mia_cbam_channel_fwd: null");
+    MIA_CHECK_ARG(B > 0 && HW > 0 && C > 0 && HID > 0, "mia_cbam_channel_fwd: bad shape");
+    dim3 g(B, cdiv(C, 256));
+    if (dtype == MIA_BF16)
+        hipLaunchKernelGGL(cbam_channel_pool_kernel<bf16_t>, g, dim3(256), 0, MIA_STREAM, (const bf16_t*)x, HW, C, avg, mx, amax);
+    else
+        hipLaunchKernelGGL(cbam_channel_pool_kernel<float>, g, dim3(256), 0, MIA_STREAM, (const float*)x, HW, C, avg, mx, amax);
+    hipLaunchKernelGGL(cbam_channel_mlp_kernel, dim3(B), dim3(256), (size_t)(2 * C + HID) * 4, MIA_STREAM, avg, mx, C, HID,
+                       W1, b1, W2, b2, ha, hm, cscale);
+    MIA_CHECK_LAUNCH("mia_cbam_channel_fwd");
+    return 0;
+}
+
+// comp [B,HW,2] = (max_c, mean_c) of x*cscale; pre = conv7x7(comp); part [part_rows][2][1] for BatchNorm(1)
+extern "C" int mia_cbam_spatial_fwd(int dtype, const void* x, const float* cscale, int B, int H, int W, int C,
+                                    const float* w7, float* comp, int* cmax, float* pre, float* part, int part_rows,
+                                    void* stream) {
+    MIA_CHECK_ARG(x && cscale && w7 && comp && cmax && pre && part, "mia_cbam_spatial_fwd: null");
+    MIA_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && part_rows > 0 && part_rows <= 65535, "mia_cbam_spatial_fwd: bad shape");
+    const long long npix = (long long)B * H * W;
+    if (dtype == MIA_BF16)
+        hipLaunchKernelGGL(cbam_spatial_pool_kernel<bf16_t>, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, MIA_STREAM,
+                           (const bf16_t*)x, cscale, B, H * W, C, comp, cmax);
+    else
+        hipLaunchKernelGGL(cbam_spatial_pool_kernel<float>, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, MIA_STREAM,
+                           (const float*)x, cscale, B, H * W, C, comp, cmax);
+    hipLaunchKernelGGL(cbam_spatial_conv_kernel, dim3(part_rows), dim3(256), 0, MIA_STREAM, comp, B, H, W, w7, pre, part);
+    MIA_CHECK_LAUNCH("mia_cbam_spatial_fwd");
+    return 0;
+}
+
+// out = x * cscale * sigmoid(pre*bnst[0] + bnst[1]); sgate [B,HW] stored
+extern "C" int mia_cbam_apply(int dtype, const void* x, const float* cscale, const float* pre, const float* bnst, int B,
+                              int HW, int C, void* out, float* sgate, void* stream) {
+    MIA_CHECK_ARG(x && cscale && pre && bnst && out && sgate && C % 4 == 0, "mia_cbam_apply: bad arguments");
+    const unsigned g = grid1d((long long)B * HW * C / 4);
+    if (dtype == MIA_BF16)
+        hipLaunchKernelGGL(cbam_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, MIA_STREAM, (const bf16_t*)x, cscale, pre, bnst,
+                           B, HW, C, (bf16_t*)out, sgate);
+    else
+        hipLaunchKernelGGL(cbam_apply_kernel<float>, dim3(g), dim3(256), 0, MIA_STREAM, (const float*)x, cscale, pre, bnst, B,
+                           HW, C, (float*)out, sgate);
+    MIA_CHECK_LAUNCH("mia_cbam_apply");
+    return 0;
+}
+
+// full CBAM backward. ws: fp32 scratch of at least 4*B*H*W + 4*B*C + 2*B*HID floats.
+extern "C" int mia_cbam_bwd(int dtype, const void* dx2, const void* x, int B, int H, int W, int C, int HID,
+                            const float* cscale, const float* sgate, const float* pre, const float* bnst,
+                            const float* bn_gamma, int bn_training, const float* comp, const int* cmax,
+                            const int* amax, const float* avg, const float* mx, const float* ha, const float* hm,
+                            const float* W1, const float* W2, const float* w7, float* ws, void* dx, float* dW1,
+                            float* db1, float* dW2, float* db2, float* dw7, float* dbn_gamma, float* dbn_beta,
+                            void* stream) {
+    MIA_CHECK_ARG(dx2 && x && cscale && sgate && pre && bnst && bn_gamma && comp && cmax && amax && avg && mx && ha &&
+                      hm && W1 && W2 && w7 && ws && dx && dW1 && db1 && dW2 && db2 && dw7 && dbn_gamma && dbn_beta,
+                  "mia_cbam_bwd: null argument");
+    MIA_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && HID > 0, "mia_cbam_bwd: bad shape");
+    const int HW = H * W;
+    const long long npix = (long long)B * HW;
+    float* dsg = ws;                 // [npix]
+    float* dpre = dsg + npix;        // [npix]
+    float* dcomp = dpre + npix;      // [npix][2]
+    float* dcs = dcomp + 2 * npix;   // [B][C]
+    float* datt = dcs + (size_t)B * C;
+    float* davg = datt + (size_t)B * C;
+    float* dmax = davg + (size_t)B * C;   // caller sized ws for 4*npix + 4*B*C + 2*B*HID
+    float* dpa = dmax + (size_t)B * C;
+    float* dpm = dpa + (size_t)B * HID;
+    hipStream_t s = MIA_STREAM;
+    const unsigned gp = (unsigned)((npix + 3) / 4);
+    if (dtype == MIA_BF16)
+        hipLaunchKernelGGL(cbam_bwd_dsgate_kernel<bf16_t>, dim3(gp), dim3(256), 0, s, (const bf16_t*)dx2, (const bf16_t*)x,
+                           cscale, B, HW, C, dsg);
+    else
+        hipLaunchKernelGGL(cbam_bwd_dsgate_kernel<float>, dim3(gp), dim3(256), 0, s, (const float*)dx2, (const float*)x,
+                           cscale, B, HW, C, dsg);
+    hipLaunchKernelGGL(cbam_bwd_spatial_bn_kernel, dim3(1), dim3(1024), 0, s, dsg, sgate, pre, bnst, bn_gamma,
+                       bn_training, npix, dpre, dbn_gamma, dbn_beta);
+    hipLaunchKernelGGL(cbam_bwd_conv_weight_kernel, dim3(98), dim3(256), 0, s, dpre, comp, B, H, W, dw7);
+    hipLaunchKernelGGL(cbam_bwd_conv_data_kernel, dim3(grid1d(npix)), dim3(256), 0, s, dpre, B, H, W, w7, dcomp);
+    dim3 gc(B, cdiv(C, 256));
+    if (dtype == MIA_BF16)
+        hipLaunchKernelGGL(cbam_bwd_dcs_kernel<bf16_t>, gc, dim3(256), 0, s, (const bf16_t*)dx2, (const bf16_t*)x, sgate,
+                           dcomp, cmax, HW, C, dcs);
+    else
+        hipLaunchKernelGGL(cbam_bwd_dcs_kernel<float>, gc, dim3(256), 0, s, (const float*)dx2, (const float*)x, sgate, dcomp,
+                           cmax, HW, C, dcs);
+    hipLaunchKernelGGL(cbam_bwd_mlp_kernel, dim3(B), dim3(256), (size_t)(C + 2 * HID) * 4, s, dcs, cscale, ha, hm, C, HID, W1,
+                       W2, datt, dpa, dpm, davg, dmax);
+    hipLaunchKernelGGL(cbam_bwd_mlp_param_kernel, dim3(cdiv((long long)C * HID, 256)), dim3(256), 0, s, B, C, HID, datt, dpa,
+                       dpm, ha, hm, avg, mx, dW1, db1, dW2, db2);
+    const unsigned ge = grid1d((long long)B * HW * C);
+    if (dtype == MIA_BF16)
+        hipLaunchKernelGGL(cbam_bwd_dx_kernel<bf16_t>, dim3(ge), dim3(256), 0, s, (const bf16_t*)dx2, sgate, dcomp, cmax,
+                           cscale, davg, dmax, amax, B, HW, C, (bf16_t*)dx);
+    else
+        hipLaunchKernelGGL(cbam_bwd_dx_kernel<float>, dim3(ge), dim3(256), 0, s, (const float*)dx2, sgate, dcomp, cmax, cscale,
+                           davg, dmax, amax, B, HW, C, (float*)dx);
+    MIA_CHECK_LAUNCH("mia_cbam_bwd");
+    return 0;
+}
+
+template <typename T>
+static int launch_attention(bool fwd, const void* qkv, const float* P, const void* dout, int B, int HW, int C, int heads,
+                            float pdrop, unsigned long long seed, float* Pout, void* out, hipStream_t s) {
+    const int HD = C / heads;
+    const float scale = 1.0f / sqrtf((float)HD);
+    const size_t lds = ((size_t)2 * HW * HD + (fwd ? 0 : HW)) * 4;
+    dim3 grid(B * heads);
+#define MIA_ATT(HD_)                                                                                                  \
+    do {                                                                                                              \
+        if (fwd) {                                                                                                    \
+            auto k = attention_fwd_kernel<T, HD_>;                                                                    \
+            if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const T*)qkv, HW, C, heads, scale, pdrop, seed, Pout, (T*)out); \
+        } else {                                                                                                      \
+            auto k = attention_bwd_kernel<T, HD_>;                                                                    \
+            if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const T*)qkv, P, (const T*)dout, HW, C, heads, scale, pdrop, seed, (T*)out); \
+        }                                                                                                             \
+    } while (0)
+    if (HD == 48) MIA_ATT(48);
+    else if (HD == 8) MIA_ATT(8);
+    else if (HD == 16) MIA_ATT(16);
+    else if (HD == 32) MIA_ATT(32);
+    else if (HD == 64) MIA_ATT(64);
+    else return -1;
+#undef MIA_ATT
+    return 0;
+}
+
+static int attention_checks(const char* name, int B, int HW, int C, int heads) {
+    MIA_CHECK_ARG(B > 0 && HW > 0 && HW <= 256 && C > 0 && heads > 0 && C % heads == 0,
+                  "%s: bad shape B=%d tokens=%d C=%d heads=%d (tokens <= 256)", name, B, HW, C, heads);
+    const int hd = C / heads;
+    MIA_CHECK_ARG(hd == 8 || hd == 16 || hd == 32 || hd == 48 || hd == 64, "%s: head_dim %d not built (8,16,32,48,64)", name, hd);
+    return 0;
+}
+
+// qkv [B*HW, 3C] -> out [B*HW, C]; P [B,heads,HW,HW] fp32 softmax weights kept for the backward pass
+extern "C" int mia_attention_fwd(int dtype, const void* qkv, int B, int HW, int C, int heads, float pdrop,
+                                 unsigned long long seed, float* P, void* out, void* stream) {
+    if (attention_checks("mia_attention_fwd", B, HW, C, heads)) return -1;
+    MIA_CHECK_ARG(qkv && P && out, "mia_attention_fwd: null");
+    int rc = dtype == MIA_BF16
+                 ? launch_attention<bf16_t>(true, qkv, nullptr, nullptr, B, HW, C, heads, pdrop, seed, P, out, MIA_STREAM)
+                 : launch_attention<float>(true, qkv, nullptr, nullptr, B, HW, C, heads, pdrop, seed, P, out, MIA_STREAM);
+    MIA_CHECK_ARG(rc == 0, "mia_attention_fwd: dispatch failed");
+    MIA_CHECK_LAUNCH("mia_attention_fwd");
+    return 0;
+}
+
+extern "C" int mia_attention_bwd(int dtype, const void* qkv, const float* P, const void* dout, int B, int HW, int C,
+                                 int heads, float pdrop, unsigned long long seed, void* dqkv, void* stream) {
+    if (attention_checks("mia_attention_bwd", B, HW, C, heads)) return -1;
+    MIA_CHECK_ARG(qkv && P && dout && dqkv, "mia_attention_bwd: null");
+    int rc = dtype == MIA_BF16
+                 ? launch_attention<bf16_t>(false, qkv, P, dout, B, HW, C, heads, pdrop, seed, nullptr, dqkv, MIA_STREAM)
+                 : launch_attention<float>(false, qkv, P, dout, B, HW, C, heads, pdrop, seed, nullptr, dqkv, MIA_STREAM);
+    MIA_CHECK_ARG(rc == 0, "mia_attention_bwd: dispatch failed");
+    MIA_CHECK_LAUNCH("mia_attention_bwd");
+    return 0;
+}
+
+extern "C" int mia_pool_ln_dropout_fwd(const float* in_part, int B, int S, int HW, int C, const float* gamma,
+                                       const float* beta, float eps, float pdrop, unsigned long long seed, float* out,
+                                       float* xhat, float* rstd, void* stream) {
+    MIA_CHECK_ARG(in_part && out && xhat && rstd && B > 0 && S > 0 && HW > 0 && C > 0, "mia_pool_ln_dropout_fwd: bad arguments");
+    MIA_CHECK_ARG(!(gamma == nullptr) == !(beta == nullptr), "mia_pool_ln_dropout_fwd: gamma/beta come together");
+    hipLaunchKernelGGL(pool_ln_dropout_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, MIA_STREAM, in_part, B, S, C,
+                       1.0f / (float)HW, gamma, beta, eps, pdrop, seed, out, xhat, rstd);
+    MIA_CHECK_LAUNCH("mia_pool_ln_dropout_fwd");
+    return 0;
+}
+
+extern "C" int mia_pool_ln_dropout_bwd(const float* dout, int B, int C, const float* gamma, const float* xhat,
+                                       const float* rstd, float pdrop, unsigned long long seed, float* dpooled,
+                                       float* dgamma_rows, float* dbeta_rows, void* stream) {
+    MIA_CHECK_ARG(dout && dpooled && B > 0 && C > 0, "mia_pool_ln_dropout_bwd: bad arguments");
+    MIA_CHECK_ARG(!gamma || (xhat && rstd && dgamma_rows && dbeta_rows), "mia_pool_ln_dropout_bwd: LayerNorm needs its state");
+    hipLaunchKernelGGL(pool_ln_dropout_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, MIA_STREAM, dout, B, C, gamma, xhat, rstd,
+                       pdrop, seed, dpooled, dgamma_rows, dbeta_rows);
+    MIA_CHECK_LAUNCH("mia_pool_ln_dropout_bwd");
+    return 0;
+}
+
+extern "C" int mia_broadcast_rows(int dtype, const float* v, int B, int HW, int C, float mult, const void* res,
+                                  void* out, void* stream) {
+    MIA_CHECK_ARG(v && out && B > 0 && HW > 0 && C > 0 && C % 4 == 0, "mia_broadcast_rows: bad arguments");
+    const unsigned g = grid1d((long long)B * HW * C / 4);
+    if (dtype == MIA_BF16)
+        hipLaunchKernelGGL(broadcast_rows_kernel<bf16_t>, dim3(g), dim3(256), 0, MIA_STREAM, v, B, HW, C, mult,
+                           (const bf16_t*)res, (bf16_t*)out);
+    else
+        hipLaunchKernelGGL(broadcast_rows_kernel<float>, dim3(g), dim3(256), 0, MIA_STREAM, v, B, HW, C, mult,
+                           (const float*)res, (float*)out);
+    MIA_CHECK_LAUNCH("mia_broadcast_rows");
+    return 0;
+}
+
+extern "C" int mia_dropout_f32(float* x, const float* relu_ref, long long n, float pdrop, unsigned long long seed,
+                               void* stream) {
+    MIA_CHECK_ARG(x && n > 0, "mia_dropout_f32: bad arguments");
+    hipLaunchKernelGGL(dropout_f32_kernel, dim3(grid1d(n)), dim3(256), 0, MIA_STREAM, x, relu_ref, n, pdrop, seed);
+    MIA_CHECK_LAUNCH("mia_dropout_f32");
+    return 0;
+}
+
+extern "C" int mia_colsum(int dtype, const void* x, long long R, int C, int ld, float* out, void* stream) {
+    MIA_CHECK_ARG(x && out && R > 0 && C > 0 && ld >= C, "mia_colsum: bad arguments");
+    if (dtype == MIA_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(cdiv(C, 64)), dim3(256), 0, MIA_STREAM, (const bf16_t*)x, R, C, ld, out);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(C, 64)), dim3(256), 0, MIA_STREAM, (const float*)x, R, C, ld, out);
+    MIA_CHECK_LAUNCH("mia_colsum");
+    return 0;
+}
+
+extern "C" int mia_softmax_ce(const float* logits, int ld, const long long* labels, int B, int n, float* loss,
+                              float* dlogits, int ldd, void* stream) {
+    MIA_CHECK_ARG(logits && labels && loss && dlogits && B > 0 && n > 0 && ld >= n && ldd >= n, "mia_softmax_ce: bad arguments");
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, MIA_STREAM, logits, labels, B, n, ld, loss, dlogits, ldd);
+    MIA_CHECK_LAUNCH("mia_softmax_ce");
+    return 0;
+}

@@ -1,0 +1,120 @@
+"""GPU parity of the head kernels against golden vectors produced by the REFERENCE's own classes
+(tests/golden/make_golden.py ran CBAM / MultiHeadAttentionClassifier / the simple head of
+/root/reference/foundation_model/src/model.py on CPU). fp32: outputs within 1e-4, gradients within 1e-3,
+relative to each tensor's largest magnitude."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import mia_amd  # noqa: E402,F401
+from mia_amd import head_ops  # noqa: E402
+from mia_amd.heads import CBAM, MultiHeadAttentionClassifier, SimpleHead  # noqa: E402
+from seeding import load_seeded, randn  # noqa: E402
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def digest(t):
+    f = t.detach().double().flatten().cpu()
+    head = f[:16].numpy()
+    if head.size < 16:
+        head = np.pad(head, (0, 16 - head.size))
+    return np.concatenate([[f.sum().item(), f.norm().item()], head])
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def check(mod, x_nchw, gold, train, out_is_map, zero_grad_params=()):
+    mod = mod.cuda().train(train)
+    x = nhwc(x_nchw).cuda().requires_grad_(True)
+    out = mod(x)
+    out_cmp = out.permute(0, 3, 1, 2) if out_is_map else out
+    assert rel(out_cmp, gold["out"]) < 1e-4
+    if not train:
+        return
+    g = randn(777, *gold["out"].shape)
+    out.backward((nhwc(g) if out_is_map else g).cuda())
+    assert rel(x.grad.permute(0, 3, 1, 2), gold["dx"]) < 1e-3
+    for k, p in mod.named_parameters():
+        ref = gold["grad." + k]
+        assert p.grad is not None, k
+        if any(z in k for z in zero_grad_params):
+            # the true gradient is exactly zero (softmax is invariant to a key bias): both sides hold noise
+            assert p.grad.abs().max().item() < 1e-5, k
+            continue
+        if ref.shape == tuple(p.shape):
+            assert rel(p.grad, ref) < 1e-3, k
+        else:
+            d = digest(p.grad)
+            assert abs(d[0] - ref[0]) <= 1e-3 * max(abs(ref[1]), 1e-12) + 1e-6, k      # sum vs l2 scale
+            assert abs(d[1] - ref[1]) <= 1e-3 * abs(ref[1]) + 1e-9, k                   # l2 norm
+            assert np.abs(d[2:] - ref[2:]).max() <= 1e-3 * max(np.abs(ref[2:]).max(), abs(ref[1]) * 1e-3), k
+    for k, b in mod.named_buffers():
+        if "running" in k:
+            assert rel(b, gold["buf." + k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("c,hw,tag", [(384, 10, "c384_10x10"), (64, 2, "c64_2x2"), (64, 5, "c64_5x5")])
+@pytest.mark.parametrize("train", [True, False])
+def test_cbam_matches_reference(c, hw, tag, train):
+    gold = np.load(os.path.join(G, f"cbam_{tag}_{'train' if train else 'eval'}.npz"))
+    check(load_seeded(CBAM(c), 11), randn(12, 2, c, hw, hw), gold, train, True)
+
+
+@pytest.mark.parametrize("c,hw,n,tag", [(384, 10, 4, "c384_10x10"), (384, 2, 4, "c384_2x2"), (64, 3, 2, "c64_3x3")])
+@pytest.mark.parametrize("train", [True, False])
+def test_mha_head_matches_reference(c, hw, n, tag, train):
+    gold = np.load(os.path.join(G, f"mha_{tag}_{'train' if train else 'eval'}.npz"))
+    m = load_seeded(MultiHeadAttentionClassifier(c, 8, n, dropout=0.0), 21)
+    check(m, randn(22, 2, c, hw, hw), gold, train, False, zero_grad_params=("key.bias",))
+
+
+def test_simple_head_matches_reference():
+    gold = np.load(os.path.join(G, "simple_c384_10x10_train.npz"))
+    check(load_seeded(SimpleHead(384, 4, 0.0), 31), randn(32, 2, 384, 10, 10), gold, True, False)
+
+
+def test_cross_entropy_matches_torch():
+    logits = randn(1, 37, 4).cuda().requires_grad_(True)
+    labels = torch.from_numpy(np.random.default_rng(2).integers(0, 4, 37)).cuda()
+    loss = head_ops.CrossEntropyLoss()(logits, labels)
+    loss.backward()
+    ref_l = logits.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ref_l, labels)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item()))
+    assert rel(logits.grad, ref_l.grad) < 1e-5
+
+
+def test_dropout_statistics_and_determinism():
+    """Train-mode dropout (p=0.2): kept fraction ~0.8, kept values scaled by 1/0.8, same mask in backward."""
+    x = torch.ones(1 << 16, device="cuda", requires_grad=True)
+    y = head_ops.DropoutFn.apply(x, 0.2, 12345)
+    kept = (y > 0).float().mean().item()
+    assert abs(kept - 0.8) < 0.01
+    assert torch.allclose(y[y > 0], torch.full_like(y[y > 0], 1.25))
+    y.sum().backward()
+    assert torch.equal(x.grad, y.detach())
+    y2 = head_ops.DropoutFn.apply(x, 0.2, 12346)
+    assert not torch.equal(y2, y)
+
+
+def test_mha_head_bf16_close_to_fp32():
+    m = load_seeded(MultiHeadAttentionClassifier(384, 8, 4, dropout=0.0), 21).cuda().eval()
+    x = nhwc(randn(22, 4, 384, 10, 10)).cuda()
+    with torch.no_grad():
+        a = m(x)
+        b = m(x.bfloat16())
+    assert rel(b, a) < 3e-2
