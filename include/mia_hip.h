@@ -55,9 +55,11 @@ int mia_dwconv_fwd(int dtype, const void* x, int B, int H, int W, int C, const f
 int mia_dwconv_bwd_data(int dtype, const void* dy, int B, int H, int W, int C, const float* w, int K, int S, void* dx,
                         const void* yfwd, const float* escale, const float* eshift, const float* emean,
                         const float* erstd, float* stats, int part_rows, void* stream);
-/* dw[C][k*k] (fp32) += sum dy * pro(x); dw must be zero-filled first. */
+/* dw[C][k*k] (fp32) = sum dy * pro(x). ws: fp32 scratch of ws_floats >= C*k*k floats (256*C*k*k lets every
+ * workgroup row keep its own partial; fewer rows are used when it is smaller). */
 int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int W, int C, const float* pscale,
-                          const float* pshift, const void* dy, int K, int S, float* dw, void* stream);
+                          const float* pshift, const void* dy, int K, int S, float* dw, float* ws,
+                          long long ws_floats, void* stream);
 
 /* ---- BatchNorm: timm BatchNormAct2d (eps 1e-5, momentum 0.1) and CBAM's nn.BatchNorm2d(1, momentum 0.01)
  *      (src/model.py:16) ------------------------------------------------------------------------------------
@@ -85,11 +87,13 @@ int mia_affine2(int dtype, const void* X, const void* Y, const void* Res, void* 
  * out[b][split][c] = sum over the split's rows of Wt[r,c] * act(Y*scale+shift)   (Wt optional) */
 int mia_img_colsum(int dtype, const void* Y, const void* Wt, int B, int HW, int C, const float* scale,
                    const float* shift, int act, int splits, float* out, void* stream);
+/* Wr = conv_reduce.weight [RD][C]; WeT = conv_expand.weight TRANSPOSED to [RD][C] (coalesced reads); gradients
+ * dWr [RD][C] and dWe [C][RD] come back in the parameters' own layouts. */
 int mia_se_gate_fwd(const float* pool_part, int B, int splits, int HW, int C, int RD, const float* Wr,
-                    const float* br, const float* We, const float* be, float* pooled, float* hpre, float* gate,
+                    const float* br, const float* WeT, const float* be, float* pooled, float* hpre, float* gate,
                     void* stream);
 int mia_se_gate_bwd(const float* dgate_part, int B, int splits, int HW, int C, int RD, const float* Wr,
-                    const float* We, const float* gate, const float* hpre, const float* pooled, float* dpre2,
+                    const float* WeT, const float* gate, const float* hpre, const float* pooled, float* dpre2,
                     float* dpre1, float* dpool, float* dWr, float* dbr, float* dWe, float* dbe, void* stream);
 
 /* ---- CBAM (src/model.py:28-108) on an NHWC feature map x [B,H*W,C] -----------------------------------------

@@ -9,7 +9,7 @@
 //   dwconv_fwd        y = dw(pro(x))                      + per-channel sum/sumsq partials (BN stats)
 //   data-gradient     stride 1: the same kernel with flipped taps; stride 2: gather kernel
 //                     both with the fused epilogue g = dA * silu'(z), partials sum(g), sum(g*xhat)
-//   dwconv_bwd_weight dW[c][kh][kw] += sum dY * pro(x)    (fp32 atomics)
+//   dwconv_bwd_weight dW[c][kh][kw] = sum dY * pro(x)     (per-workgroup partial slab + ordered reduce)
 #include "common.h"
 
 #define DW_PW 4  // output pixels per strip
@@ -348,9 +348,19 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, cons
             const int v_ = tid >> 2, e = tid & 3;
             float a = 0.f;
             for (int q_ = 0; q_ < npt; ++q_) a += red[(q_ * nvec + v_) * 4 + e];
-            atomicAdd(dw + (size_t)(c0 + tid) * (K * K) + t, a);
+            // slab row of this workgroup: [gridDim.x][C][K*K]; one plain store per output, no contention
+            dw[((size_t)blockIdx.x * p.C + c0 + tid) * (K * K) + t] = a;
         }
     }
+}
+
+// out[i] = sum over rows of slab[row][i]  (fixed order => reproducible)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int rows, long long n, float* out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.f;
+    for (int r = 0; r < rows; ++r) a += slab[(size_t)r * n + i];
+    out[i] = a;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -482,12 +492,15 @@ extern "C" int mia_dwconv_bwd_data(int dtype, const void* dy, int B, int H, int 
     return 0;
 }
 
-// dw [C][K*K] fp32 must be zero-filled (or hold a gradient to accumulate into) before the call.
+// dw [C][K*K] fp32 is overwritten. ws: fp32 scratch; every workgroup row writes its partial [C][K*K] there and a
+// second kernel sums the rows. The number of rows adapts to ws_floats (at least one row = C*K*K floats).
 extern "C" int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int W, int C, const float* pscale,
-                                     const float* pshift, const void* dy, int K, int S, float* dw, void* stream) {
+                                     const float* pshift, const void* dy, int K, int S, float* dw, float* ws,
+                                     long long ws_floats, void* stream) {
     if (dw_common_checks("mia_dwconv_bwd_weight", dtype, B, H, W, C, K, S)) return -1;
-    MIA_CHECK_ARG(x && dy && dw, "mia_dwconv_bwd_weight: null operand");
+    MIA_CHECK_ARG(x && dy && dw && ws, "mia_dwconv_bwd_weight: null operand");
     MIA_CHECK_ARG(!(pscale == nullptr) == !(pshift == nullptr), "mia_dwconv_bwd_weight: pscale/pshift come together");
+    MIA_CHECK_ARG(ws_floats >= (long long)C * K * K, "mia_dwconv_bwd_weight: workspace smaller than one partial row");
     DwParams p = {};
     p.x = x; p.B = B; p.H = H; p.W = W; p.C = C;
     const int pad = (K - 1) / 2;
@@ -497,12 +510,17 @@ extern "C" int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int
     pick_tile(p.OH, p.OW, K, S, p.CB, elem, 1, dtype == MIA_BF16 ? 40960 : 49152, &p.TH, &p.TW);
     p.tiles_h = cdiv(p.OH, p.TH); p.tiles_w = cdiv(p.OW, p.TW);
     const int total = B * p.tiles_h * p.tiles_w;
-    const int gx = total < 1024 ? total : 1024;
+    const int ncb = cdiv(C, p.CB);
+    long long gx = 1024 / ncb;                      // ~1024 workgroups in all
+    if (gx < 8) gx = 8;
+    if (gx > 256) gx = 256;
+    if (gx > total) gx = total;
+    if (gx > ws_floats / ((long long)C * K * K)) gx = ws_floats / ((long long)C * K * K);
     const int IHT = (p.TH - 1) * S + K, IWT = (p.TW - 1) * S + K;
     const size_t lds = 256 * 4 * 4 + ((size_t)IHT * IWT + (size_t)p.TH * p.TW) * p.CB * elem;
-    dim3 grid(gx, cdiv(C, p.CB));
+    dim3 grid((unsigned)gx, ncb);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define MIA_DWW(T_, K_, S_) hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T_, K_, S_>), grid, dim3(256), lds, s, p, dy, dw)
+#define MIA_DWW(T_, K_, S_) hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T_, K_, S_>), grid, dim3(256), lds, s, p, dy, ws)
     if (dtype == MIA_BF16) {
         if (K == 3 && S == 1) MIA_DWW(bf16_t, 3, 1);
         else if (K == 3 && S == 2) MIA_DWW(bf16_t, 3, 2);
@@ -515,6 +533,8 @@ extern "C" int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int
         else MIA_DWW(float, 5, 2);
     }
 #undef MIA_DWW
+    const long long nout = (long long)C * K * K;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, s, ws, (int)gx, nout, dw);
     MIA_CHECK_LAUNCH("mia_dwconv_bwd_weight");
     return 0;
 }

@@ -603,17 +603,22 @@ __global__ __launch_bounds__(256) void dropout_f32_kernel(float* x, const float*
     }
 }
 
-// column sums of an fp32 [R, C] matrix (bias gradients). grid = ceil(C/64); fixed order.
+// column sums of an [R, C] matrix (bias gradients). grid = (ceil(C/64), row_chunks); the row chunks add their
+// partial with one float atomic per column (out is zero-filled by the launcher).
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* x, long long R, int C, int ld, float* out) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const long long rows_per = (R + gridDim.y - 1) / gridDim.y;
+    const long long r0 = (long long)blockIdx.y * rows_per;
+    const long long r1 = (r0 + rows_per) < R ? (r0 + rows_per) : R;
     float s = 0.f;
     if (c < C)
-        for (long long r = w; r < R; r += 4) s += to_f32<T>(x[(size_t)r * ld + c]);
+        for (long long r = r0 + w; r < r1; r += 4) s += to_f32<T>(x[(size_t)r * ld + c]);
     red[w][threadIdx.x & 63] = s;
     __syncthreads();
-    if (w == 0 && c < C) out[c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (w == 0 && c < C)
+        atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // softmax cross-entropy, mean over the batch, with its gradient (d loss / d logits). One workgroup.
@@ -864,10 +869,16 @@ extern "C" int mia_dropout_f32(float* x, const float* relu_ref, long long n, flo
 
 extern "C" int mia_colsum(int dtype, const void* x, long long R, int C, int ld, float* out, void* stream) {
     MIA_CHECK_ARG(x && out && R > 0 && C > 0 && ld >= C, "mia_colsum: bad arguments");
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)C * sizeof(float), MIA_STREAM);
+    MIA_CHECK_ARG(e == hipSuccess, "mia_colsum: memset failed: %s", hipGetErrorString(e));
+    long long chunks = R / 64;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 128) chunks = 128;
+    dim3 grid(cdiv(C, 64), (unsigned)chunks);
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(cdiv(C, 64)), dim3(256), 0, MIA_STREAM, (const bf16_t*)x, R, C, ld, out);
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, MIA_STREAM, (const bf16_t*)x, R, C, ld, out);
     else
-        hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(C, 64)), dim3(256), 0, MIA_STREAM, (const float*)x, R, C, ld, out);
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, MIA_STREAM, (const float*)x, R, C, ld, out);
     MIA_CHECK_LAUNCH("mia_colsum");
     return 0;
 }

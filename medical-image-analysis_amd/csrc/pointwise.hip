@@ -299,13 +299,32 @@ __global__ __launch_bounds__(256) void img_colsum_kernel(const T* Y, const T* Wt
     if (m.valid) {
         f4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
         if (scale) { sc = load4<float>(scale + m.c); sh = load4<float>(shift + m.c); }
-        for (int r = r_begin + m.pt; r < r_end; r += m.npt) {
-            const size_t idx = ((size_t)b * HW + r) * C + m.c;
-            f4 y = load4<T>(Y + idx);
+        const T* yb = Y + (size_t)b * HW * C + m.c;
+        const T* wb = Wt ? Wt + (size_t)b * HW * C + m.c : nullptr;
+        int r = r_begin + m.pt;
+        // 4 independent rows per iteration keep several loads in flight per lane
+        for (; r + 3 * m.npt < r_end; r += 4 * m.npt) {
+            f4 y[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) y[u] = load4<T>(yb + (size_t)(r + u * m.npt) * C);
+            if (wb) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w[u] = load4<T>(wb + (size_t)(r + u * m.npt) * C);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                f4 v = {y[u].x * sc.x + sh.x, y[u].y * sc.y + sh.y, y[u].z * sc.z + sh.z, y[u].w * sc.w + sh.w};
+                if (act == MIA_ACT_SILU) { v.x = siluf_(v.x); v.y = siluf_(v.y); v.z = siluf_(v.z); v.w = siluf_(v.w); }
+                if (wb) { v.x *= w[u].x; v.y *= w[u].y; v.z *= w[u].z; v.w *= w[u].w; }
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        }
+        for (; r < r_end; r += m.npt) {
+            f4 y = load4<T>(yb + (size_t)r * C);
             y.x = y.x * sc.x + sh.x; y.y = y.y * sc.y + sh.y; y.z = y.z * sc.z + sh.z; y.w = y.w * sc.w + sh.w;
             if (act == MIA_ACT_SILU) { y.x = siluf_(y.x); y.y = siluf_(y.y); y.z = siluf_(y.z); y.w = siluf_(y.w); }
-            if (Wt) {
-                const f4 w = load4<T>(Wt + idx);
+            if (wb) {
+                const f4 w = load4<T>(wb + (size_t)r * C);
                 y.x *= w.x; y.y *= w.y; y.z *= w.z; y.w *= w.w;
             }
             s.x += y.x; s.y += y.y; s.z += y.z; s.w += y.w;
@@ -319,8 +338,9 @@ extern "C" int mia_img_colsum(int dtype, const void* Y, const void* Wt, int B, i
     MIA_CHECK_ARG(Y && out && B > 0 && HW > 0 && C > 0 && C % 4 == 0 && splits > 0 && splits <= HW,
                   "mia_img_colsum: bad arguments");
     MIA_CHECK_ARG(!(scale == nullptr) == !(shift == nullptr), "mia_img_colsum: scale/shift must come together");
-    int ncb, CB;
-    host_colblock(C, &ncb, &CB);
+    // at most 256 channels (64 vectors = one wave per row segment) per workgroup column: >= 4 row-threads
+    const int ncb = cdiv(C, 256);
+    const int CB = cdiv(cdiv(C, 4), ncb) * 4;
     dim3 grid(B * splits, ncb);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIA_BF16)
@@ -337,7 +357,7 @@ extern "C" int mia_img_colsum(int dtype, const void* Y, const void* Wt, int B, i
 // squeeze-excite gate: pooled -> FC(rd)+SiLU -> FC(C)+sigmoid.  One workgroup per image.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* pool_part, int splits, float inv_hw, int C,
-                                                          int RD, const float* Wr, const float* br, const float* We,
+                                                          int RD, const float* Wr, const float* br, const float* WeT,
                                                           const float* be, float* pooled, float* hpre, float* gate) {
     extern __shared__ float sm[];
     float* pl = sm;      // [C]
@@ -364,19 +384,19 @@ __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* pool_part
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         float d = be[c];
-        for (int j = 0; j < RD; ++j) d += We[(size_t)c * RD + j] * h[j];
+        for (int j = 0; j < RD; ++j) d += WeT[(size_t)j * C + c] * h[j];
         gate[(size_t)b * C + c] = sigmoidf_(d);
     }
 }
 
 extern "C" int mia_se_gate_fwd(const float* pool_part, int B, int splits, int HW, int C, int RD, const float* Wr,
-                               const float* br, const float* We, const float* be, float* pooled, float* hpre,
+                               const float* br, const float* WeT, const float* be, float* pooled, float* hpre,
                                float* gate, void* stream) {
-    MIA_CHECK_ARG(pool_part && Wr && br && We && be && pooled && hpre && gate && B > 0 && C > 0 && RD > 0 && HW > 0,
+    MIA_CHECK_ARG(pool_part && Wr && br && WeT && be && pooled && hpre && gate && B > 0 && C > 0 && RD > 0 && HW > 0,
                   "mia_se_gate_fwd: bad arguments");
     const size_t lds = (size_t)(C + RD) * 4;
     hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), pool_part,
-                       splits, 1.0f / (float)HW, C, RD, Wr, br, We, be, pooled, hpre, gate);
+                       splits, 1.0f / (float)HW, C, RD, Wr, br, WeT, be, pooled, hpre, gate);
     MIA_CHECK_LAUNCH("mia_se_gate_fwd");
     return 0;
 }
@@ -384,7 +404,7 @@ extern "C" int mia_se_gate_fwd(const float* pool_part, int B, int splits, int HW
 // backward through the gate for one image: dgate (summed partials) -> dpre2 [B,C], dpre1 [B,RD],
 // dpool [B,C] (already divided by HW: it is added to every pixel's gradient)
 __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* dgate_part, int splits, float inv_hw, int C,
-                                                          int RD, const float* Wr, const float* We, const float* gate,
+                                                          int RD, const float* Wr, const float* WeT, const float* gate,
                                                           const float* hpre, float* dpre2, float* dpre1, float* dpool) {
     extern __shared__ float sm[];
     float* d2 = sm;      // [C]
@@ -401,7 +421,7 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* dgate_par
     __syncthreads();
     for (int j = wave; j < RD; j += 4) {
         float d = 0.f;
-        for (int c = lane; c < C; c += 64) d += We[(size_t)c * RD + j] * d2[c];
+        for (int c = lane; c < C; c += 64) d += WeT[(size_t)j * C + c] * d2[c];
         d = wave_sum(d);
         if (lane == 0) {
             const float v = d * silu_gradf_(hpre[(size_t)b * RD + j]);
@@ -417,40 +437,50 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* dgate_par
     }
 }
 
-// parameter gradients of the two FCs, summed over the batch (fixed order => reproducible)
+// parameter gradients of the two FCs, summed over the batch (fixed order => reproducible).
+// 64 (c, j) pairs per workgroup; the 4 waves split the batch and combine through LDS.
 __global__ __launch_bounds__(256) void se_param_grad_kernel(int B, int C, int RD, const float* dpre2,
                                                             const float* dpre1, const float* pooled, const float* hpre,
                                                             float* dWr, float* dbr, float* dWe, float* dbe) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= C * RD) return;
+    __shared__ float red[4][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    const bool ok = i < C * RD;
     // i = c*RD + j addresses We[c][j]; the same thread also produces Wr[j][c]
-    const int c = i / RD, j = i % RD;
+    const int c = ok ? i / RD : 0, j = ok ? i % RD : 0;
     float we = 0.f, wr = 0.f, bE = 0.f, bR = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float p2 = dpre2[(size_t)b * C + c], p1 = dpre1[(size_t)b * RD + j];
-        we += p2 * siluf_(hpre[(size_t)b * RD + j]);
-        wr += p1 * pooled[(size_t)b * C + c];
-        bE += p2;
-        bR += p1;
+    if (ok) {
+#pragma unroll 4
+        for (int b = wave; b < B; b += 4) {
+            const float p2 = dpre2[(size_t)b * C + c], p1 = dpre1[(size_t)b * RD + j];
+            we += p2 * siluf_(hpre[(size_t)b * RD + j]);
+            wr += p1 * pooled[(size_t)b * C + c];
+            bE += p2;
+            bR += p1;
+        }
     }
-    dWe[(size_t)c * RD + j] = we;
-    dWr[(size_t)j * C + c] = wr;
-    if (j == 0) dbe[c] = bE;
-    if (c == 0) dbr[j] = bR;
+    red[0][wave][lane] = we; red[1][wave][lane] = wr; red[2][wave][lane] = bE; red[3][wave][lane] = bR;
+    __syncthreads();
+    if (wave == 0 && ok) {
+        dWe[(size_t)c * RD + j] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+        dWr[(size_t)j * C + c] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+        if (j == 0) dbe[c] = red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane];
+        if (c == 0) dbr[j] = red[3][0][lane] + red[3][1][lane] + red[3][2][lane] + red[3][3][lane];
+    }
 }
 
 extern "C" int mia_se_gate_bwd(const float* dgate_part, int B, int splits, int HW, int C, int RD, const float* Wr,
-                               const float* We, const float* gate, const float* hpre, const float* pooled,
+                               const float* WeT, const float* gate, const float* hpre, const float* pooled,
                                float* dpre2, float* dpre1, float* dpool, float* dWr, float* dbr, float* dWe,
                                float* dbe, void* stream) {
-    MIA_CHECK_ARG(dgate_part && Wr && We && gate && hpre && pooled && dpre2 && dpre1 && dpool && dWr && dbr && dWe &&
+    MIA_CHECK_ARG(dgate_part && Wr && WeT && gate && hpre && pooled && dpre2 && dpre1 && dpool && dWr && dbr && dWe &&
                       dbe && B > 0 && C > 0 && RD > 0 && HW > 0,
                   "mia_se_gate_bwd: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const size_t lds = (size_t)(C + RD) * 4;
     hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(256), lds, s, dgate_part, splits, 1.0f / (float)HW, C, RD, Wr,
-                       We, gate, hpre, dpre2, dpre1, dpool);
-    hipLaunchKernelGGL(se_param_grad_kernel, dim3(cdiv((long long)C * RD, 256)), dim3(256), 0, s, B, C, RD, dpre2,
+                       WeT, gate, hpre, dpre2, dpre1, dpool);
+    hipLaunchKernelGGL(se_param_grad_kernel, dim3(cdiv((long long)C * RD, 64)), dim3(256), 0, s, B, C, RD, dpre2,
                        dpre1, pooled, hpre, dWr, dbr, dWe, dbe);
     MIA_CHECK_LAUNCH("mia_se_gate_bwd");
     return 0;

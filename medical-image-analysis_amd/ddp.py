@@ -42,7 +42,7 @@ class GradReducer:
         for p in plist:
             views[id(p)] = flat[off:off + p.numel()].view_as(p)
             off += p.numel()
-        b = {"flat": flat, "views": views, "count": len(plist), "pending": len(plist)}
+        b = {"flat": flat, "views": views, "count": len(plist), "pending": len(plist), "ready": []}
         for p in plist:
             self._param_bucket[id(p)] = b
         self.buckets.append(b)
@@ -55,14 +55,24 @@ class GradReducer:
             dist.broadcast(t.data, src, group=self.group)
 
     def _hook(self, p: torch.nn.Parameter):
+        if self.world == 1:
+            return  # nothing to exchange: gradients stay where autograd put them
         b = self._param_bucket[id(p)]
-        v = b["views"][id(p)]
-        v.copy_(p.grad)
-        p.grad = v
+        b["ready"].append(p)
         b["pending"] -= 1
-        if b["pending"] == 0 and self.world > 1:
-            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-            self._works.append((dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True), b))
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        # one fused multi-tensor copy packs the bucket, then its all-reduce starts while backward continues
+        ready = b["ready"]
+        views = [b["views"][id(p)] for p in ready]
+        torch._foreach_copy_(views, [p.grad for p in ready])
+        for p, v in zip(ready, views):
+            p.grad = v
+        b["ready"] = []
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self._works.append((dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True), b))
 
     def finish(self):
         """Wait for every outstanding bucket, flush buckets whose parameters got no gradient this step."""
@@ -70,8 +80,7 @@ class GradReducer:
             for b in self.buckets:
                 if 0 < b["pending"] < b["count"]:
                     # some parameters of this bucket were unused: their slots hold zeros
-                    op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-                    self._works.append((dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True), b))
+                    self._launch(b)
             for w, b in self._works:
                 w.wait()
                 if not self._avg:
@@ -81,12 +90,13 @@ class GradReducer:
             b["pending"] = b["count"]
 
     def zero_grad(self):
-        """Keep the gradient views alive (cheap memset of the flat buckets) instead of freeing them."""
-        for b in self.buckets:
-            b["flat"].zero_()
+        """Drop last step's gradients; with several ranks also clear the flat buckets (slots of parameters that
+        receive no gradient must contribute zeros to the reduction)."""
+        if self.world > 1:
+            for b in self.buckets:
+                b["flat"].zero_()
         for p in self.params:
-            if p.grad is not None and id(p) in self._param_bucket:
-                p.grad = None
+            p.grad = None
 
     def remove(self):
         for h in self._handles:

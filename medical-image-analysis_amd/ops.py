@@ -125,10 +125,12 @@ def dwconv_bwd_data(dy, w, k, s, in_hw, *, yfwd=None, escale=None, eshift=None, 
 
 def dwconv_bwd_weight(x, dy, k, s, *, pscale=None, pshift=None):
     B, H, W, C = x.shape
-    dw = torch.zeros((C, 1, k, k), dtype=torch.float32, device=x.device)
+    dw = torch.empty((C, 1, k, k), dtype=torch.float32, device=x.device)
+    ncb = -(-C // (64 if C % 64 == 0 else 48 if C % 48 == 0 else min(C, 64)))
+    ws = torch.empty((max(8, min(256, 1024 // ncb)) * C * k * k,), dtype=torch.float32, device=x.device)
     _launch("dwconv_bwd_weight", (x.numel() + dy.numel()) * x.element_size(), lib().mia_dwconv_bwd_weight,
-            _DT[x.dtype], _p(x), B, H, W, C, _p(pscale), _p(pshift), _p(dy), k, s, _p(dw),
-                                _stream())
+            _DT[x.dtype], _p(x), B, H, W, C, _p(pscale), _p(pshift), _p(dy), k, s, _p(dw), _p(ws), ws.numel(),
+            _stream())
     return dw
 
 
@@ -189,26 +191,27 @@ def affine2(x, a, d, *, y=None, b=None, res=None, act=ACT_NONE, out=None):
 def img_colsum(y, wt, scale, shift, act):
     B, H, W, C = y.shape
     HW = H * W
-    splits = max(1, min(16, HW // 1024))
+    ncb = -(-C // 256)
+    splits = max(1, min(HW // 64, 64, -(-2048 // (B * ncb))))  # ~2048 workgroups, >= 64 rows each
     out = torch.empty((B, splits, C), dtype=torch.float32, device=y.device)
     _launch("img_colsum", y.numel() * y.element_size() * (2 if wt is not None else 1), lib().mia_img_colsum,
             _DT[y.dtype], _p(y), _p(wt), B, HW, C, _p(scale), _p(shift), act, splits, _p(out), _stream())
     return out
 
 
-def se_gate_fwd(pool_part, hw, wr, br, we, be):
+def se_gate_fwd(pool_part, hw, wr, br, weT, be):
     B, splits, C = pool_part.shape
     RD = wr.shape[0]
     dev = pool_part.device
     pooled = torch.empty((B, C), dtype=torch.float32, device=dev)
     hpre = torch.empty((B, RD), dtype=torch.float32, device=dev)
     gate = torch.empty((B, C), dtype=torch.float32, device=dev)
-    lib().mia_se_gate_fwd(_p(pool_part), B, splits, hw, C, RD, _p(wr), _p(br), _p(we), _p(be), _p(pooled), _p(hpre),
+    lib().mia_se_gate_fwd(_p(pool_part), B, splits, hw, C, RD, _p(wr), _p(br), _p(weT), _p(be), _p(pooled), _p(hpre),
                           _p(gate), _stream())
     return pooled, hpre, gate
 
 
-def se_gate_bwd(dgate_part, hw, wr, we, gate, hpre, pooled):
+def se_gate_bwd(dgate_part, hw, wr, weT, gate, hpre, pooled):
     B, splits, C = dgate_part.shape
     RD = wr.shape[0]
     dev = dgate_part.device
@@ -217,9 +220,9 @@ def se_gate_bwd(dgate_part, hw, wr, we, gate, hpre, pooled):
     dpool = torch.empty((B, C), dtype=torch.float32, device=dev)
     dwr = torch.empty_like(wr)
     dbr = torch.empty((RD,), dtype=torch.float32, device=dev)
-    dwe = torch.empty_like(we)
+    dwe = torch.empty((C, RD), dtype=torch.float32, device=dev)
     dbe = torch.empty((C,), dtype=torch.float32, device=dev)
-    lib().mia_se_gate_bwd(_p(dgate_part), B, splits, hw, C, RD, _p(wr), _p(we), _p(gate), _p(hpre), _p(pooled),
+    lib().mia_se_gate_bwd(_p(dgate_part), B, splits, hw, C, RD, _p(wr), _p(weT), _p(gate), _p(hpre), _p(pooled),
                           _p(dpre2), _p(dpre1), _p(dpool), _p(dwr), _p(dbr), _p(dwe), _p(dbe), _stream())
     return dpool, dwr, dbr, dwe, dbe
 
@@ -322,8 +325,9 @@ class MBConvFn(torch.autograd.Function):
         st2 = bn_finalize_fwd(part, M2, cfg.bn_dw)
         # ---- squeeze-excite ----
         pool_part = img_colsum(y2, None, st2[0], st2[1], ACT_SILU)
-        wr, we = _w2d(w_ser), _w2d(w_see)
-        pooled, hpre, gate = se_gate_fwd(pool_part, OH * OW, wr, b_ser.detach(), we, b_see.detach())
+        wr = _w2d(w_ser)
+        _, weT = cast_weight(_w2d(w_see), torch.float32, want=False, want_t=True)  # [RD, Cm]
+        pooled, hpre, gate = se_gate_fwd(pool_part, OH * OW, wr, b_ser.detach(), weT, b_see.detach())
         # ---- projection ----
         wproj, _ = cast_weight(_w2d(w_proj), dt)
         y3, part = gemm_nt(y2.view(M2, Cm), wproj, pscale=st2[0], pshift=st2[1], pro_act=ACT_SILU, gate=gate,
@@ -361,8 +365,9 @@ class MBConvFn(torch.autograd.Function):
         dz = dz.view(B, OH, OW, Cm)
         # ---- squeeze-excite backward ----
         dgate_part = img_colsum(y2, dz, st2[0], st2[1], ACT_SILU)
-        wr, we = _w2d(w_ser), _w2d(w_see)
-        dpool, dwr, dbr, dwe, dbe = se_gate_bwd(dgate_part, OH * OW, wr, we, gate, hpre, pooled)
+        wr = _w2d(w_ser)
+        _, weT = cast_weight(_w2d(w_see), torch.float32, want=False, want_t=True)  # [RD, Cm]
+        dpool, dwr, dbr, dwe, dbe = se_gate_bwd(dgate_part, OH * OW, wr, weT, gate, hpre, pooled)
         # ---- bn after depthwise (+SiLU) ----
         part = bn_act_bwd_reduce(dz, y2, st2, ACT_SILU, gate=gate, dpool=dpool, rows_per_img=OH * OW)
         c2 = bn_finalize_bwd(part, M2, g2, st2, training)

@@ -246,7 +246,8 @@ def test_se_gate_fwd_bwd(C, RD, B, hw):
     pool_part = rnd(B, 3, C, seed=1)
     wr, br = rnd(RD, C, seed=2, scale=C ** -0.5), rnd(RD, seed=3, scale=0.1)
     we, be = rnd(C, RD, seed=4, scale=RD ** -0.5), rnd(C, seed=5, scale=0.1)
-    pooled, hpre, gate = ops.se_gate_fwd(pool_part, hw, wr, br, we, be)
+    weT = we.t().contiguous()
+    pooled, hpre, gate = ops.se_gate_fwd(pool_part, hw, wr, br, weT, be)
     pp = pool_part.clone().requires_grad_(True)
     wr_, br_, we_, be_ = [t.clone().requires_grad_(True) for t in (wr, br, we, be)]
     p_ref = pp.sum(1) / hw
@@ -254,7 +255,7 @@ def test_se_gate_fwd_bwd(C, RD, B, hw):
     assert relerr(gate, g_ref) < 1e-5 and relerr(pooled, p_ref) < 1e-5
     dgate_part = rnd(B, 2, C, seed=6)
     g_ref.backward(dgate_part.sum(1))
-    dpool, dwr, dbr, dwe, dbe = ops.se_gate_bwd(dgate_part, hw, wr, we, gate, hpre, pooled)
+    dpool, dwr, dbr, dwe, dbe = ops.se_gate_bwd(dgate_part, hw, wr, weT, gate, hpre, pooled)
     # dpool is the per-pixel gradient: d/d(sum over pixels) / hw  == pp.grad of any split
     assert relerr(dpool, pp.grad[:, 0]) < 1e-4
     for mine, ref in ((dwr, wr_.grad), (dbr, br_.grad), (dwe, we_.grad), (dbe, be_.grad)):
