@@ -1,18 +1,20 @@
 // Depthwise k x k convolutions (k in {3,5}, stride in {1,2}) on NHWC tensors, gfx950.
 //
-// A workgroup owns a (TH x TW output pixels) x (CB channels) tile of one image. The input halo tile
-// is staged once into LDS -- with the producer's BatchNorm+SiLU applied on the way in, so the
-// normalised activation never exists in HBM -- and every thread computes strips of 4 output pixels
-// for one 4-channel vector, re-using each staged input row across the k taps along W. Lanes run
-// fastest over channels, so global loads/stores are contiguous CB*sizeof(T) byte runs per pixel.
+// A workgroup owns a (TH x TW output pixels) x (CB channels) tile of one image. The input halo tile is staged
+// once into LDS -- with the producer's BatchNorm+SiLU applied on the way in, so the normalised activation never
+// exists in HBM -- and every thread computes PH x 4 output patches for ONE 4-channel vector (fixed for the whole
+// kernel, so its BN constants live in registers). Each staged input row of a patch is read once and used for
+// every tap row that touches it; tap vectors are re-read from LDS (broadcast across pixel-threads). Lanes run fastest over channels, so global
+// loads/stores are contiguous CB*sizeof(T)-byte runs per pixel. Index arithmetic in the inner loops is
+// incremental: no integer division.
 //
 //   dwconv_fwd        y = dw(pro(x))                      + per-channel sum/sumsq partials (BN stats)
-//   data-gradient     stride 1: the same kernel with flipped taps; stride 2: gather kernel
+//   data-gradient     stride 1: the same kernel with flipped taps; stride 2: row-gather kernel
 //                     both with the fused epilogue g = dA * silu'(z), partials sum(g), sum(g*xhat)
 //   dwconv_bwd_weight dW[c][kh][kw] = sum dY * pro(x)     (per-workgroup partial slab + ordered reduce)
 #include "common.h"
 
-#define DW_PW 4  // output pixels per strip
+#define DW_PW 4  // output pixels per patch row
 
 struct DwParams {
     const void* x;
@@ -31,12 +33,16 @@ struct DwParams {
     int CB, TH, TW, tiles_h, tiles_w;
 };
 
+__device__ __forceinline__ void fma4(f4& acc, const f4& a, const f4& b) {
+    acc.x += a.x * b.x; acc.y += a.y * b.y; acc.z += a.z * b.z; acc.w += a.w * b.w;
+}
+
 template <typename T>
-__device__ __forceinline__ void dw_epilogue_store(const DwParams& p, size_t idx, int c, f4 v, f4 es, f4 eh, f4 em,
-                                                  f4 er, f4& s, f4& q) {
+__device__ __forceinline__ void dw_epilogue_store(const DwParams& p, unsigned idx, f4 v, const f4& es, const f4& eh,
+                                                  const f4& em, const f4& er, f4& s, f4& q) {
     T* y = reinterpret_cast<T*>(p.y);
     if (p.yfwd) {
-        f4 yv = load4<T>(reinterpret_cast<const T*>(p.yfwd) + idx);
+        const f4 yv = load4<T>(reinterpret_cast<const T*>(p.yfwd) + idx);
         f4 g;
         g.x = v.x * silu_gradf_(yv.x * es.x + eh.x);
         g.y = v.y * silu_gradf_(yv.y * es.y + eh.y);
@@ -74,10 +80,54 @@ __device__ __forceinline__ void dw_write_stats(const DwParams& p, float* red, in
     }
 }
 
-template <typename T, int K, int S>
+// Stage a [rows x cols] pixel window of one image, for this thread's channel vector, into LDS with the optional
+// BatchNorm+SiLU prologue. Thread (pt, cv) walks pixels pt, pt+npt, ... keeping (row, col) incrementally; U
+// independent loads are issued before any is consumed.
+template <typename T, int U>
+__device__ __forceinline__ void dw_stage_tile(const T* __restrict__ img, T* tile, int rows, int cols, int r0, int c0px,
+                                              int H, int W, int C, int cg, bool chan_ok, int cv, int pt, int npt,
+                                              int CB, bool has_pro, const f4& psc, const f4& psh) {
+    if (pt >= npt) return;
+    const int npix = rows * cols;
+    int pix = pt;
+    int row = pt / cols, col = pt - row * cols;   // one division per tile, not per pixel
+    const int drow = npt / cols, dcol = npt - drow * cols;
+    while (pix < npix) {
+        f4 v[U];
+        int pixs[U];
+        bool inb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pixs[u] = pix;
+            const int ih = r0 + row, iw = c0px + col;
+            inb[u] = pix < npix && chan_ok && ih >= 0 && ih < H && iw >= 0 && iw < W;
+            v[u] = f4{0.f, 0.f, 0.f, 0.f};
+            if (inb[u]) v[u] = load4<T>(img + (unsigned)((ih * W + iw) * C + cg));
+            pix += npt;
+            row += drow;
+            col += dcol;
+            if (col >= cols) { col -= cols; ++row; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (pixs[u] < npix) {
+                if (has_pro && inb[u]) {
+                    v[u].x = siluf_(v[u].x * psc.x + psh.x);
+                    v[u].y = siluf_(v[u].y * psc.y + psh.y);
+                    v[u].z = siluf_(v[u].z * psc.z + psh.z);
+                    v[u].w = siluf_(v[u].w * psc.w + psh.w);
+                }
+                store4<T>(tile + (unsigned)(pixs[u] * CB + cv * 4), v[u]);
+            }
+        }
+    }
+}
+
+template <typename T, int K, int S, int PH>
 __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
     constexpr int PAD = (K - 1) / 2;
-    constexpr int NIN = (DW_PW - 1) * S + K;
+    constexpr int NIN = (DW_PW - 1) * S + K;   // staged input pixels per patch row
+    constexpr int NIR = (PH - 1) * S + K;      // staged input rows per patch
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int CB = p.CB, TH = p.TH, TW = p.TW;
     const int IHT = (TH - 1) * S + K, IWT = (TW - 1) * S + K;
@@ -92,100 +142,97 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
     const int nvec = CB / 4, npt = 256 / nvec;
     const int cv = tid % nvec, pt = tid / nvec;
     const int c = c0 + cv * 4;
-    const bool cvalid = (cv * 4 < cbv) && (pt < npt);
+    const bool chan_ok = cv * 4 < cbv;
+    const bool cvalid = chan_ok && (pt < npt);
     const bool has_pro = p.pscale != nullptr;
 
     for (int i = tid; i < K * K * CB; i += 256) {
-        const int t = i / CB, cc = i % CB;
+        const int t = i / CB, cc = i - t * CB;
         const int ts = p.flip ? (K * K - 1 - t) : t;
         wsm[i] = (cc < cbv) ? p.w[(size_t)(c0 + cc) * (K * K) + ts] : 0.f;
     }
     f4 psc = {1, 1, 1, 1}, psh = {0, 0, 0, 0};
-    // the loader's channel vector is (item % nvec) == tid % nvec because 256 % nvec may be != 0;
-    // so the loader recomputes its vector per item (below) and reads scale/shift from global/L1.
+    if (has_pro && chan_ok) { psc = load4<float>(p.pscale + c); psh = load4<float>(p.pshift + c); }
     f4 es = {0, 0, 0, 0}, eh = es, em = es, er = es;
     if (p.yfwd && cvalid) {
         es = load4<float>(p.escale + c); eh = load4<float>(p.eshift + c);
         em = load4<float>(p.emean + c); er = load4<float>(p.erstd + c);
     }
     f4 st_s = {0, 0, 0, 0}, st_q = {0, 0, 0, 0};
-
+    __syncthreads();
     const int tiles_per_img = p.tiles_h * p.tiles_w;
     const int total = p.B * tiles_per_img;
-    const int strips_w = TW / DW_PW;
-    const int nstrips = TH * strips_w;
+    const int patches_w = TW / DW_PW, patches_h = TH / PH;
+    const int npatch = patches_h * patches_w;
+    const int dph = npt / patches_w, dpw = npt - dph * patches_w;
 
     for (int work = blockIdx.x; work < total; work += gridDim.x) {
         const int b = work / tiles_per_img;
-        const int tr = work % tiles_per_img;
-        const int oh0 = (tr / p.tiles_w) * TH, ow0 = (tr % p.tiles_w) * TW;
-        const int ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
-        __syncthreads();  // previous tile fully consumed (and wsm written, first time)
-        // ---- stage the input halo tile ----
-        const int items = IHT * IWT * nvec;
-        for (int it = tid; it < items; it += 256) {
-            const int v_ = it % nvec, pix = it / nvec;
-            const int ih = ih0 + pix / IWT, iw = iw0 + pix % IWT;
-            f4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && v_ * 4 < cbv) {
-                const int cg = c0 + v_ * 4;
-                v = load4<T>(x + (((size_t)b * p.H + ih) * p.W + iw) * p.C + cg);
-                if (has_pro) {
-                    psc = load4<float>(p.pscale + cg);
-                    psh = load4<float>(p.pshift + cg);
-                    v.x = siluf_(v.x * psc.x + psh.x);
-                    v.y = siluf_(v.y * psc.y + psh.y);
-                    v.z = siluf_(v.z * psc.z + psh.z);
-                    v.w = siluf_(v.w * psc.w + psh.w);
-                }
-            }
-            store4<T>(tile + (size_t)pix * CB + v_ * 4, v);
-        }
+        const int tr = work - b * tiles_per_img;
+        const int trh = tr / p.tiles_w;
+        const int oh0 = trh * TH, ow0 = (tr - trh * p.tiles_w) * TW;
+        __syncthreads();  // previous tile fully consumed
+        dw_stage_tile<T, (sizeof(T) == 2 ? 8 : 4)>(x + (size_t)b * p.H * p.W * p.C, tile, IHT, IWT, oh0 * S - PAD,
+                                                    ow0 * S - PAD, p.H, p.W, p.C, c, chan_ok, cv, pt, npt, CB, has_pro,
+                                                    psc, psh);
         __syncthreads();
         if (cvalid) {
-            for (int strip = pt; strip < nstrips; strip += npt) {
-                const int ohl = strip / strips_w, owl = (strip % strips_w) * DW_PW;
-                f4 acc[DW_PW];
+            int ph = pt / patches_w, pw = pt - ph * patches_w;
+            for (int patch = pt; patch < npatch; patch += npt) {
+                const int ohl = ph * PH, owl = pw * DW_PW;
+                f4 acc[PH][DW_PW];
 #pragma unroll
-                for (int q_ = 0; q_ < DW_PW; ++q_) acc[q_] = f4{0.f, 0.f, 0.f, 0.f};
+                for (int a = 0; a < PH; ++a)
+#pragma unroll
+                    for (int q_ = 0; q_ < DW_PW; ++q_) acc[a][q_] = f4{0.f, 0.f, 0.f, 0.f};
+                // one staged input row at a time (a real loop: keeps the live set to one row + the accumulators);
+                // the row feeds every output row of the patch whose tap row kh = ir - a*S is in range
+                const T* row = tile + (unsigned)(((ohl * S) * IWT + owl * S) * CB + cv * 4);
 #pragma unroll 1
-                for (int kh = 0; kh < K; ++kh) {
-                    const T* row = tile + ((size_t)(ohl * S + kh) * IWT + owl * S) * CB + cv * 4;
+                for (int ir = 0; ir < NIR; ++ir, row += IWT * CB) {
                     f4 in[NIN];
 #pragma unroll
                     for (int j = 0; j < NIN; ++j) in[j] = load4<T>(row + j * CB);
 #pragma unroll
-                    for (int kw = 0; kw < K; ++kw) {
-                        const f4 wv = load4<float>(wsm + (kh * K + kw) * CB + cv * 4);
+                    for (int a = 0; a < PH; ++a) {
+                        const int kh = ir - a * S;
+                        if (kh >= 0 && kh < K) {
+                            const float* wrow = wsm + (unsigned)(kh * K * CB + cv * 4);
+#pragma unroll
+                            for (int kw = 0; kw < K; ++kw) {
+                                const f4 wv = load4<float>(wrow + kw * CB);
+#pragma unroll
+                                for (int q_ = 0; q_ < DW_PW; ++q_) fma4(acc[a][q_], in[q_ * S + kw], wv);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < PH; ++a) {
+                    const int oh = oh0 + ohl + a;
+                    if (oh < p.OH) {
 #pragma unroll
                         for (int q_ = 0; q_ < DW_PW; ++q_) {
-                            const f4 a = in[q_ * S + kw];
-                            acc[q_].x += a.x * wv.x;
-                            acc[q_].y += a.y * wv.y;
-                            acc[q_].z += a.z * wv.z;
-                            acc[q_].w += a.w * wv.w;
+                            const int ow = ow0 + owl + q_;
+                            if (ow < p.OW) {
+                                const unsigned idx = (unsigned)(((b * p.OH + oh) * p.OW + ow) * p.C + c);
+                                dw_epilogue_store<T>(p, idx, acc[a][q_], es, eh, em, er, st_s, st_q);
+                            }
                         }
                     }
                 }
-                const int oh = oh0 + ohl;
-                if (oh < p.OH) {
-#pragma unroll
-                    for (int q_ = 0; q_ < DW_PW; ++q_) {
-                        const int ow = ow0 + owl + q_;
-                        if (ow < p.OW) {
-                            const size_t idx = (((size_t)b * p.OH + oh) * p.OW + ow) * p.C + c;
-                            dw_epilogue_store<T>(p, idx, c, acc[q_], es, eh, em, er, st_s, st_q);
-                        }
-                    }
-                }
+                ph += dph;
+                pw += dpw;
+                if (pw >= patches_w) { pw -= patches_w; ++ph; }
             }
         }
     }
     if (p.stats) dw_write_stats(p, red, tid, nvec, npt, c0, cbv, st_s, st_q);
 }
 
-// stride-S data gradient by gathering: dA[ih,iw,c] = sum_{kh,kw} dY[(ih+PAD-kh)/S, (iw+PAD-kw)/S, c] * w[c,kh,kw]
-template <typename T, int K, int S>
+// stride-2 data gradient by gathering, one image row per workgroup iteration:
+//   dA[ih,iw,c] = sum_{kh,kw} dY[(ih+PAD-kh)/2, (iw+PAD-kw)/2, c] * w[c,kh,kw]  over the taps with even offsets
+template <typename T, int K>
 __global__ __launch_bounds__(256) void dwconv_bwd_data_gather_kernel(DwParams p) {
     // here: p.x = dY [B,OH,OW,C]; p.y = dA [B,H,W,C]; p.yfwd = forward raw input-side tensor [B,H,W,C]
     constexpr int PAD = (K - 1) / 2;
@@ -202,7 +249,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_gather_kernel(DwParams p)
     const int c = c0 + cv * 4;
     const bool cvalid = (cv * 4 < cbv) && (pt < npt);
     for (int i = tid; i < K * K * CB; i += 256) {
-        const int t = i / CB, cc = i % CB;
+        const int t = i / CB, cc = i - t * CB;
         wsm[i] = (cc < cbv) ? p.w[(size_t)(c0 + cc) * (K * K) + t] : 0.f;
     }
     f4 es = {0, 0, 0, 0}, eh = es, em = es, er = es;
@@ -212,40 +259,41 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_gather_kernel(DwParams p)
     }
     f4 st_s = {0, 0, 0, 0}, st_q = {0, 0, 0, 0};
     __syncthreads();
-    const long long npix = (long long)p.B * p.H * p.W;
+    const int nrows = p.B * p.H;
     if (cvalid) {
-        for (long long pix = (long long)blockIdx.x * npt + pt; pix < npix; pix += (long long)gridDim.x * npt) {
-            const int iw = (int)(pix % p.W);
-            const int ih = (int)((pix / p.W) % p.H);
-            const int b = (int)(pix / ((long long)p.W * p.H));
-            f4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int rowi = blockIdx.x; rowi < nrows; rowi += gridDim.x) {
+            const int b = rowi / p.H, ih = rowi - b * p.H;   // wave-uniform: scalar arithmetic
+            for (int iw = pt; iw < p.W; iw += npt) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kh = 0; kh < K; ++kh) {
-                const int th = ih + PAD - kh;
-                if (th < 0 || (th % S) != 0) continue;
-                const int oh = th / S;
-                if (oh >= p.OH) continue;
+                for (int kh = 0; kh < K; ++kh) {
+                    const int th = ih + PAD - kh;
+                    if (th < 0 || (th & 1)) continue;
+                    const int oh = th >> 1;
+                    if (oh >= p.OH) continue;
 #pragma unroll
-                for (int kw = 0; kw < K; ++kw) {
-                    const int tw = iw + PAD - kw;
-                    if (tw < 0 || (tw % S) != 0) continue;
-                    const int ow = tw / S;
-                    if (ow >= p.OW) continue;
-                    const f4 g = load4<T>(dy + (((size_t)b * p.OH + oh) * p.OW + ow) * p.C + c);
-                    const f4 wv = load4<float>(wsm + (kh * K + kw) * CB + cv * 4);
-                    acc.x += g.x * wv.x; acc.y += g.y * wv.y; acc.z += g.z * wv.z; acc.w += g.w * wv.w;
+                    for (int kw = 0; kw < K; ++kw) {
+                        const int tw = iw + PAD - kw;
+                        if (tw < 0 || (tw & 1)) continue;
+                        const int ow = tw >> 1;
+                        if (ow >= p.OW) continue;
+                        const f4 g = load4<T>(dy + (unsigned)(((b * p.OH + oh) * p.OW + ow) * p.C + c));
+                        fma4(acc, g, load4<float>(wsm + (kh * K + kw) * CB + cv * 4));
+                    }
                 }
+                const unsigned idx = (unsigned)((rowi * p.W + iw) * p.C + c);
+                dw_epilogue_store<T>(p, idx, acc, es, eh, em, er, st_s, st_q);
             }
-            const size_t idx = (size_t)pix * p.C + c;
-            dw_epilogue_store<T>(p, idx, c, acc, es, eh, em, er, st_s, st_q);
         }
     }
     if (p.stats) dw_write_stats(p, red, tid, nvec, npt, c0, cbv, st_s, st_q);
 }
 
-// weight gradient: dW[c][kh][kw] += sum_{b,oh,ow} dY[b,oh,ow,c] * pro(x)[b, oh*S+kh-PAD, ow*S+kw-PAD, c]
+// weight gradient: dW[c][kh][kw] = sum_{b,oh,ow} dY[b,oh,ow,c] * pro(x)[b, oh*S+kh-PAD, ow*S+kw-PAD, c]
+// A thread owns ONE tap row kh of one 4-channel vector (K accumulators), so the register footprint stays small
+// for 5x5 kernels too; the K tap rows of a channel vector are K different threads reading the same staged tiles.
 template <typename T, int K, int S>
-__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, const void* dyv, float* dw) {
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, const void* dyv, float* slab) {
     constexpr int PAD = (K - 1) / 2;
     constexpr int NIN = (DW_PW - 1) * S + K;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -260,96 +308,77 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, cons
     const int tid = threadIdx.x;
     const int c0 = blockIdx.y * CB;
     const int cbv = (p.C - c0) < CB ? (p.C - c0) : CB;
-    const int nvec = CB / 4, npt = 256 / nvec;
-    const int cv = tid % nvec, pt = tid / nvec;
-    const bool cvalid = (cv * 4 < cbv) && (pt < npt);
+    const int nvec = CB / 4;
+    // staging map: (pixel-thread, channel vector)
+    const int s_npt = 256 / nvec, s_cv = tid % nvec, s_pt = tid / nvec;
+    const bool s_chan_ok = s_cv * 4 < cbv;
     const bool has_pro = p.pscale != nullptr;
+    f4 psc = {1, 1, 1, 1}, psh = {0, 0, 0, 0};
+    if (has_pro && s_chan_ok) { psc = load4<float>(p.pscale + c0 + s_cv * 4); psh = load4<float>(p.pshift + c0 + s_cv * 4); }
+    const f4 one = {1, 1, 1, 1}, zero = {0, 0, 0, 0};
+    // compute map: (pixel-thread, tap row, channel vector)
+    const int nkc = K * nvec, npt = 256 / nkc;
+    const int cv = tid % nvec, kh = (tid / nvec) % K, pt = tid / nkc;
+    const bool cvalid = (cv * 4 < cbv) && (pt < npt);
 
-    f4 acc[K * K];
+    f4 acc[K];
 #pragma unroll
-    for (int t = 0; t < K * K; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < K; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
 
     const int tiles_per_img = p.tiles_h * p.tiles_w;
     const int total = p.B * tiles_per_img;
-    const int strips_w = TW / DW_PW;
-    const int nstrips = TH * strips_w;
+    const int patches_w = TW / DW_PW;
+    const int npatch = TH * patches_w;
+    const int dph = npt / patches_w, dpw = npt - dph * patches_w;
 
     for (int work = blockIdx.x; work < total; work += gridDim.x) {
         const int b = work / tiles_per_img;
-        const int tr = work % tiles_per_img;
-        const int oh0 = (tr / p.tiles_w) * TH, ow0 = (tr % p.tiles_w) * TW;
-        const int ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
+        const int tr = work - b * tiles_per_img;
+        const int trh = tr / p.tiles_w;
+        const int oh0 = trh * TH, ow0 = (tr - trh * p.tiles_w) * TW;
         __syncthreads();
-        const int items = IHT * IWT * nvec;
-        for (int it = tid; it < items; it += 256) {
-            const int v_ = it % nvec, pix = it / nvec;
-            const int ih = ih0 + pix / IWT, iw = iw0 + pix % IWT;
-            f4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && v_ * 4 < cbv) {
-                const int cg = c0 + v_ * 4;
-                v = load4<T>(x + (((size_t)b * p.H + ih) * p.W + iw) * p.C + cg);
-                if (has_pro) {
-                    const f4 psc = load4<float>(p.pscale + cg);
-                    const f4 psh = load4<float>(p.pshift + cg);
-                    v.x = siluf_(v.x * psc.x + psh.x);
-                    v.y = siluf_(v.y * psc.y + psh.y);
-                    v.z = siluf_(v.z * psc.z + psh.z);
-                    v.w = siluf_(v.w * psc.w + psh.w);
-                }
-            }
-            store4<T>(tile + (size_t)pix * CB + v_ * 4, v);
-        }
-        const int ditems = TH * TW * nvec;
-        for (int it = tid; it < ditems; it += 256) {
-            const int v_ = it % nvec, pix = it / nvec;
-            const int oh = oh0 + pix / TW, ow = ow0 + pix % TW;
-            f4 v = {0.f, 0.f, 0.f, 0.f};
-            if (oh < p.OH && ow < p.OW && v_ * 4 < cbv)
-                v = load4<T>(dy + (((size_t)b * p.OH + oh) * p.OW + ow) * p.C + c0 + v_ * 4);
-            store4<T>(dtile + (size_t)pix * CB + v_ * 4, v);
-        }
+        dw_stage_tile<T, (sizeof(T) == 2 ? 8 : 4)>(x + (size_t)b * p.H * p.W * p.C, tile, IHT, IWT, oh0 * S - PAD,
+                                                    ow0 * S - PAD, p.H, p.W, p.C, c0 + s_cv * 4, s_chan_ok, s_cv, s_pt,
+                                                    s_npt, CB, has_pro, psc, psh);
+        dw_stage_tile<T, (sizeof(T) == 2 ? 8 : 4)>(dy + (size_t)b * p.OH * p.OW * p.C, dtile, TH, TW, oh0, ow0, p.OH,
+                                                    p.OW, p.C, c0 + s_cv * 4, s_chan_ok, s_cv, s_pt, s_npt, CB, false,
+                                                    one, zero);
         __syncthreads();
         if (cvalid) {
-            for (int strip = pt; strip < nstrips; strip += npt) {
-                const int ohl = strip / strips_w, owl = (strip % strips_w) * DW_PW;
-                f4 g[DW_PW];
+            int ph = pt / patches_w, pw = pt - ph * patches_w;
+            for (int patch = pt; patch < npatch; patch += npt) {
+                const int owl = pw * DW_PW;
+                const T* grow = dtile + (unsigned)((ph * TW + owl) * CB + cv * 4);
+                const T* row = tile + (unsigned)(((ph * S + kh) * IWT + owl * S) * CB + cv * 4);
+                f4 g[DW_PW], in[NIN];
 #pragma unroll
-                for (int q_ = 0; q_ < DW_PW; ++q_)
-                    g[q_] = load4<T>(dtile + ((size_t)ohl * TW + owl + q_) * CB + cv * 4);
+                for (int q_ = 0; q_ < DW_PW; ++q_) g[q_] = load4<T>(grow + q_ * CB);
 #pragma unroll
-                for (int kh = 0; kh < K; ++kh) {
-                    const T* row = tile + ((size_t)(ohl * S + kh) * IWT + owl * S) * CB + cv * 4;
-                    f4 in[NIN];
+                for (int j = 0; j < NIN; ++j) in[j] = load4<T>(row + j * CB);
 #pragma unroll
-                    for (int j = 0; j < NIN; ++j) in[j] = load4<T>(row + j * CB);
+                for (int kw = 0; kw < K; ++kw)
 #pragma unroll
-                    for (int kw = 0; kw < K; ++kw) {
-#pragma unroll
-                        for (int q_ = 0; q_ < DW_PW; ++q_) {
-                            const f4 a = in[q_ * S + kw];
-                            acc[kh * K + kw].x += a.x * g[q_].x;
-                            acc[kh * K + kw].y += a.y * g[q_].y;
-                            acc[kh * K + kw].z += a.z * g[q_].z;
-                            acc[kh * K + kw].w += a.w * g[q_].w;
-                        }
-                    }
-                }
+                    for (int q_ = 0; q_ < DW_PW; ++q_) fma4(acc[kw], in[q_ * S + kw], g[q_]);
+                ph += dph;
+                pw += dpw;
+                if (pw >= patches_w) { pw -= patches_w; ++ph; }
             }
         }
     }
-    // reduce over the pixel-threads of each channel vector, one tap at a time
+    // reduce over the pixel-threads of each (tap row, channel vector), one tap column at a time
 #pragma unroll
-    for (int t = 0; t < K * K; ++t) {
+    for (int kw = 0; kw < K; ++kw) {
         __syncthreads();
-        red[tid * 4 + 0] = acc[t].x; red[tid * 4 + 1] = acc[t].y;
-        red[tid * 4 + 2] = acc[t].z; red[tid * 4 + 3] = acc[t].w;
+        red[tid * 4 + 0] = acc[kw].x; red[tid * 4 + 1] = acc[kw].y;
+        red[tid * 4 + 2] = acc[kw].z; red[tid * 4 + 3] = acc[kw].w;
         __syncthreads();
-        if (tid < cbv) {
-            const int v_ = tid >> 2, e = tid & 3;
+        for (int t = tid; t < K * cbv; t += 256) {
+            const int khh = t / cbv, ch = t - khh * cbv;
+            const int v_ = ch >> 2, e = ch & 3;
             float a = 0.f;
-            for (int q_ = 0; q_ < npt; ++q_) a += red[(q_ * nvec + v_) * 4 + e];
+            for (int q_ = 0; q_ < npt; ++q_) a += red[((q_ * K + khh) * nvec + v_) * 4 + e];
             // slab row of this workgroup: [gridDim.x][C][K*K]; one plain store per output, no contention
-            dw[((size_t)blockIdx.x * p.C + c0 + tid) * (K * K) + t] = a;
+            slab[((size_t)blockIdx.x * p.C + c0 + ch) * (K * K) + khh * K + kw] = a;
         }
     }
 }
@@ -375,50 +404,58 @@ static int pick_cb(int C) {
     return 8;
 }
 
-// choose the output tile: maximise useful outputs per staged input pixel within an LDS budget
-static void pick_tile(int OH, int OW, int K, int S, int CB, int elem, int extra_out_tile, int lds_budget, int* th,
-                      int* tw) {
-    static const int ths[] = {4, 5, 8, 10, 16};
-    static const int tws[] = {8, 12, 16, 20, 24, 32};
+// Choose the output tile (TH multiple of ph, TW multiple of 4): few wasted output slots, little halo, patches
+// dividing evenly over the 256/nvec pixel-threads, within an LDS budget.
+static void pick_tile(int OH, int OW, int K, int S, int CB, int elem, int ph, int extra_out_tile, int lds_budget,
+                      int* th, int* tw) {
+    static const int ths[] = {2, 4, 6, 8, 10, 12, 16, 20};
+    static const int tws[] = {4, 8, 12, 16, 20, 24, 32, 40};
+    const int npt = 256 / (CB / 4);
     double best = -1.0;
-    *th = 4; *tw = 8;
+    *th = ph; *tw = 4;
     for (int a : ths)
         for (int b : tws) {
+            if (a % ph) continue;
             const int iht = (a - 1) * S + K, iwt = (b - 1) * S + K;
-            long long bytes = (long long)iht * iwt * CB * elem + (extra_out_tile ? (long long)a * b * CB * elem : 0);
+            const long long bytes =
+                (long long)iht * iwt * CB * elem + (extra_out_tile ? (long long)a * b * CB * elem : 0);
             if (bytes > lds_budget) continue;
             const int nth = cdiv(OH, a), ntw = cdiv(OW, b);
             const double useful = (double)OH * OW;
             const double staged = (double)nth * ntw * iht * iwt;
             const double slots = (double)nth * ntw * a * b;
-            const double score = useful / staged * (useful / slots);
+            const int patches = (a / ph) * (b / 4);
+            const double balance = (double)patches / (double)(cdiv(patches, npt) * npt);
+            const double score = (useful / staged) * (useful / slots) * balance;
             if (score > best) { best = score; *th = a; *tw = b; }
         }
 }
 
-template <typename T, int K, int S>
+template <typename T, int K, int S, int PH>
 static void launch_tile(const DwParams& p, int grid_x, hipStream_t s) {
     const int IHT = (p.TH - 1) * S + K, IWT = (p.TW - 1) * S + K;
     const size_t lds = (size_t)K * K * p.CB * 4 + 256 * 8 * 4 + (size_t)IHT * IWT * p.CB * sizeof(T);
     dim3 grid(grid_x, cdiv(p.C, p.CB));
-    hipLaunchKernelGGL((dwconv_tile_kernel<T, K, S>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((dwconv_tile_kernel<T, K, S, PH>), grid, dim3(256), lds, s, p);
 }
 
 template <typename T>
 static int dispatch_tile(const DwParams& p, int K, int S, int grid_x, hipStream_t s) {
-    if (K == 3 && S == 1) launch_tile<T, 3, 1>(p, grid_x, s);
-    else if (K == 3 && S == 2) launch_tile<T, 3, 2>(p, grid_x, s);
-    else if (K == 5 && S == 1) launch_tile<T, 5, 1>(p, grid_x, s);
-    else if (K == 5 && S == 2) launch_tile<T, 5, 2>(p, grid_x, s);
+    if (K == 3 && S == 1) launch_tile<T, 3, 1, 2>(p, grid_x, s);
+    else if (K == 3 && S == 2) launch_tile<T, 3, 2, 1>(p, grid_x, s);
+    else if (K == 5 && S == 1) launch_tile<T, 5, 1, 2>(p, grid_x, s);
+    else if (K == 5 && S == 2) launch_tile<T, 5, 2, 1>(p, grid_x, s);
     else return -1;
     return 0;
 }
+static int tile_ph(int S) { return S == 1 ? 2 : 1; }
 
 static int dw_common_checks(const char* name, int dtype, int B, int H, int W, int C, int K, int S) {
     MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "%s: bad dtype %d", name, dtype);
     MIA_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "%s: bad shape B=%d H=%d W=%d C=%d (C%%4==0)", name,
                   B, H, W, C);
     MIA_CHECK_ARG((K == 3 || K == 5) && (S == 1 || S == 2), "%s: unsupported kernel %d stride %d", name, K, S);
+    MIA_CHECK_ARG((long long)B * H * W * C < (1LL << 31), "%s: tensor too large for 32-bit element offsets", name);
     return 0;
 }
 
@@ -435,12 +472,19 @@ extern "C" int mia_dwconv_fwd(int dtype, const void* x, int B, int H, int W, int
     p.pscale = pscale; p.pshift = pshift; p.flip = 0; p.stats = stats;
     p.CB = pick_cb(C);
     const int elem = dtype == MIA_BF16 ? 2 : 4;
-    pick_tile(p.OH, p.OW, K, S, p.CB, elem, 0, dtype == MIA_BF16 ? 40960 : 49152, &p.TH, &p.TW);
+    pick_tile(p.OH, p.OW, K, S, p.CB, elem, tile_ph(S), 0, dtype == MIA_BF16 ? 32768 : 49152, &p.TH, &p.TW);
     p.tiles_h = cdiv(p.OH, p.TH); p.tiles_w = cdiv(p.OW, p.TW);
     const int total = B * p.tiles_h * p.tiles_w;
     MIA_CHECK_ARG(!stats || (part_rows > 0 && part_rows <= 65535), "mia_dwconv_fwd: stats needs 0 < part_rows <= 65535");
-    const int gx = stats ? part_rows : (total < 8192 ? total : 8192);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int gx = total < 8192 ? total : 8192;
+    if (stats) {
+        if (gx > part_rows) gx = part_rows;
+        if (gx < part_rows) {  // rows no workgroup owns must still read as zero
+            hipError_t e = hipMemsetAsync(stats + (size_t)gx * 2 * C, 0, (size_t)(part_rows - gx) * 2 * C * sizeof(float), s);
+            MIA_CHECK_ARG(e == hipSuccess, "mia_dwconv_fwd: memset failed: %s", hipGetErrorString(e));
+        }
+    }
     int rc = dtype == MIA_BF16 ? dispatch_tile<bf16_t>(p, K, S, gx, s) : dispatch_tile<float>(p, K, S, gx, s);
     MIA_CHECK_ARG(rc == 0, "mia_dwconv_fwd: no kernel for K=%d S=%d", K, S);
     MIA_CHECK_LAUNCH("mia_dwconv_fwd");
@@ -466,26 +510,31 @@ extern "C" int mia_dwconv_bwd_data(int dtype, const void* dy, int B, int H, int 
     if (S == 1) {
         // correlation with flipped taps: same tiling kernel, input = dY (OHxOW == HxW), output = dA
         p.x = dy; p.y = dx; p.H = OH; p.W = OW; p.OH = H; p.OW = W; p.flip = 1;
-        pick_tile(p.OH, p.OW, K, 1, p.CB, elem, 0, dtype == MIA_BF16 ? 40960 : 49152, &p.TH, &p.TW);
+        pick_tile(p.OH, p.OW, K, 1, p.CB, elem, tile_ph(1), 0, dtype == MIA_BF16 ? 32768 : 49152, &p.TH, &p.TW);
         p.tiles_h = cdiv(p.OH, p.TH); p.tiles_w = cdiv(p.OW, p.TW);
         const int total = B * p.tiles_h * p.tiles_w;
-        const int gx = stats ? part_rows : (total < 8192 ? total : 8192);
+        int gx = total < 8192 ? total : 8192;
+        if (stats) {
+            if (gx > part_rows) gx = part_rows;
+            if (gx < part_rows) {
+                hipError_t e = hipMemsetAsync(stats + (size_t)gx * 2 * C, 0, (size_t)(part_rows - gx) * 2 * C * sizeof(float), s);
+                MIA_CHECK_ARG(e == hipSuccess, "mia_dwconv_bwd_data: memset failed: %s", hipGetErrorString(e));
+            }
+        }
         int rc = dtype == MIA_BF16 ? dispatch_tile<bf16_t>(p, K, 1, gx, s) : dispatch_tile<float>(p, K, 1, gx, s);
         MIA_CHECK_ARG(rc == 0, "mia_dwconv_bwd_data: no kernel for K=%d", K);
     } else {
         p.x = dy; p.y = dx; p.H = H; p.W = W; p.OH = OH; p.OW = OW;
-        const int nvec = p.CB / 4, npt = 256 / nvec;
-        const long long npix = (long long)B * H * W;
-        long long need = (npix + npt - 1) / npt;
-        const int gx = stats ? part_rows : (int)(need < 8192 ? need : 8192);
+        const long long nrows = (long long)B * H;
+        const int gx = stats ? part_rows : (int)(nrows < 8192 ? nrows : 8192);
         const size_t lds = (size_t)K * K * p.CB * 4 + 256 * 8 * 4;
         dim3 grid(gx, cdiv(C, p.CB));
         if (dtype == MIA_BF16) {
-            if (K == 3) hipLaunchKernelGGL((dwconv_bwd_data_gather_kernel<bf16_t, 3, 2>), grid, dim3(256), lds, s, p);
-            else hipLaunchKernelGGL((dwconv_bwd_data_gather_kernel<bf16_t, 5, 2>), grid, dim3(256), lds, s, p);
+            if (K == 3) hipLaunchKernelGGL((dwconv_bwd_data_gather_kernel<bf16_t, 3>), grid, dim3(256), lds, s, p);
+            else hipLaunchKernelGGL((dwconv_bwd_data_gather_kernel<bf16_t, 5>), grid, dim3(256), lds, s, p);
         } else {
-            if (K == 3) hipLaunchKernelGGL((dwconv_bwd_data_gather_kernel<float, 3, 2>), grid, dim3(256), lds, s, p);
-            else hipLaunchKernelGGL((dwconv_bwd_data_gather_kernel<float, 5, 2>), grid, dim3(256), lds, s, p);
+            if (K == 3) hipLaunchKernelGGL((dwconv_bwd_data_gather_kernel<float, 3>), grid, dim3(256), lds, s, p);
+            else hipLaunchKernelGGL((dwconv_bwd_data_gather_kernel<float, 5>), grid, dim3(256), lds, s, p);
         }
     }
     MIA_CHECK_LAUNCH("mia_dwconv_bwd_data");
@@ -507,7 +556,7 @@ extern "C" int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int
     p.OH = (H + 2 * pad - K) / S + 1; p.OW = (W + 2 * pad - K) / S + 1;
     p.pscale = pscale; p.pshift = pshift; p.CB = pick_cb(C);
     const int elem = dtype == MIA_BF16 ? 2 : 4;
-    pick_tile(p.OH, p.OW, K, S, p.CB, elem, 1, dtype == MIA_BF16 ? 40960 : 49152, &p.TH, &p.TW);
+    pick_tile(p.OH, p.OW, K, S, p.CB, elem, 1, 1, dtype == MIA_BF16 ? 32768 : 49152, &p.TH, &p.TW);
     p.tiles_h = cdiv(p.OH, p.TH); p.tiles_w = cdiv(p.OW, p.TW);
     const int total = B * p.tiles_h * p.tiles_w;
     const int ncb = cdiv(C, p.CB);
@@ -520,17 +569,18 @@ extern "C" int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int
     const size_t lds = 256 * 4 * 4 + ((size_t)IHT * IWT + (size_t)p.TH * p.TW) * p.CB * elem;
     dim3 grid((unsigned)gx, ncb);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define MIA_DWW(T_, K_, S_) hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T_, K_, S_>), grid, dim3(256), lds, s, p, dy, ws)
+#define MIA_DWW(T_, K_, S_, PH_) \
+    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T_, K_, S_>), grid, dim3(256), lds, s, p, dy, ws)
     if (dtype == MIA_BF16) {
-        if (K == 3 && S == 1) MIA_DWW(bf16_t, 3, 1);
-        else if (K == 3 && S == 2) MIA_DWW(bf16_t, 3, 2);
-        else if (K == 5 && S == 1) MIA_DWW(bf16_t, 5, 1);
-        else MIA_DWW(bf16_t, 5, 2);
+        if (K == 3 && S == 1) MIA_DWW(bf16_t, 3, 1, 2);
+        else if (K == 3 && S == 2) MIA_DWW(bf16_t, 3, 2, 1);
+        else if (K == 5 && S == 1) MIA_DWW(bf16_t, 5, 1, 1);
+        else MIA_DWW(bf16_t, 5, 2, 1);
     } else {
-        if (K == 3 && S == 1) MIA_DWW(float, 3, 1);
-        else if (K == 3 && S == 2) MIA_DWW(float, 3, 2);
-        else if (K == 5 && S == 1) MIA_DWW(float, 5, 1);
-        else MIA_DWW(float, 5, 2);
+        if (K == 3 && S == 1) MIA_DWW(float, 3, 1, 2);
+        else if (K == 3 && S == 2) MIA_DWW(float, 3, 2, 1);
+        else if (K == 5 && S == 1) MIA_DWW(float, 5, 1, 1);
+        else MIA_DWW(float, 5, 2, 1);
     }
 #undef MIA_DWW
     const long long nout = (long long)C * K * K;

@@ -94,6 +94,38 @@ struct Vec16<bf16_t> {
     }
 };
 
+// a 16-byte chunk held in registers between the global load and the LDS store
+typedef uint4 raw16;
+template <typename T>
+__device__ __forceinline__ void raw_unpack(const raw16& r, float* o);
+template <>
+__device__ __forceinline__ void raw_unpack<float>(const raw16& r, float* o) {
+    o[0] = __uint_as_float(r.x); o[1] = __uint_as_float(r.y); o[2] = __uint_as_float(r.z); o[3] = __uint_as_float(r.w);
+}
+template <>
+__device__ __forceinline__ void raw_unpack<bf16_t>(const raw16& r, float* o) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[2 * i] = __uint_as_float(w[i] << 16);
+        o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+template <typename T>
+__device__ __forceinline__ raw16 raw_pack(const float* o);
+template <>
+__device__ __forceinline__ raw16 raw_pack<float>(const float* o) {
+    return make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
+}
+template <>
+__device__ __forceinline__ raw16 raw_pack<bf16_t>(const float* o) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        w[i] = (uint32_t)f32_to_bf16_bits(o[2 * i]) | ((uint32_t)f32_to_bf16_bits(o[2 * i + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 struct GemmNTParams {
     const void* A;
     const void* B;
@@ -107,7 +139,8 @@ struct GemmNTParams {
     int pro_act;
     const float* bias;
     int epi_act;
-    float* stats;  // [gridDim.x][2][N] or null
+    float* stats;  // [row_slots][2][N] or null
+    int row_slots;  // persistent row slots (= partial-sum rows when stats != null)
 };
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
@@ -139,73 +172,99 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
-    const int n0 = blockIdx.y * BN;
     const int M = p.M, N = p.N, K = p.K;
+    // Workgroup -> (row slot, column tile). Blocks b and b+8 share an XCD (and its L2), so the column tiles of
+    // one row slot are placed on consecutive slots of ONE XCD: they stream the same A rows at about the same
+    // time and all but the first read them from that L2. Purely a speed choice.
+    const int ny = (N + BN - 1) / BN;
+    const int xcd = blockIdx.x & 7, sidx = blockIdx.x >> 3;
+    const int rowslot = (sidx / ny) * 8 + xcd;
+    if (rowslot >= p.row_slots) return;
+    const int n0 = (sidx % ny) * BN;
     const bool has_pro = p.pscale != nullptr;
     const bool has_gate = p.gate != nullptr;
     const int kc = (tid % CPR) * VEC;  // this thread's k-chunk offset inside a stage
+    const int rbase = tid / CPR;       // and its first row; further chunks are 256/CPR rows apart
+    constexpr int RSTEP = 256 / CPR;
+    constexpr int ACH = BM / RSTEP, BCH = BN / RSTEP;
 
     float st_sum = 0.f, st_sq = 0.f;
     const int tiles_m = (M + BM - 1) / BM;
 
-    for (int tm = blockIdx.x; tm < tiles_m; tm += gridDim.x) {
-        const int m0 = tm * BM;
-        f32x4 acc[MT][NT];
+    raw16 ra[ACH], rb[BCH];
+    auto prefetch = [&](int m0, int k0) {
+        const int gk = k0 + kc;
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < ACH; ++i) {
+            const int gm = m0 + rbase + i * RSTEP;
+            ra[i] = make_uint4(0, 0, 0, 0);
+            if (gm < M && gk < K) ra[i] = *reinterpret_cast<const raw16*>(A + (size_t)gm * p.lda + gk);
+        }
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        for (int k0 = 0; k0 < K; k0 += BK) {
-            __syncthreads();
-            const int gk = k0 + kc;
+        for (int i = 0; i < BCH; ++i) {
+            const int gn = n0 + rbase + i * RSTEP;
+            rb[i] = make_uint4(0, 0, 0, 0);
+            if (gn < N && gk < K) rb[i] = *reinterpret_cast<const raw16*>(B + (size_t)gn * p.ldb + gk);
+        }
+    };
+    auto commit = [&](int m0, int k0) {
+        const int gk = k0 + kc;
+        if ((has_pro || has_gate) && gk < K) {
             float sc[VEC], sh[VEC];
-            if (has_pro && gk < K) {
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    sc[i] = p.pscale[gk + i];
-                    sh[i] = p.pshift[gk + i];
-                }
+            for (int i = 0; i < VEC; ++i) {
+                sc[i] = has_pro ? p.pscale[gk + i] : 1.f;
+                sh[i] = has_pro ? p.pshift[gk + i] : 0.f;
             }
-            // ---- stage A (with fused prologue) ----
-            for (int c = tid; c < BM * CPR; c += 256) {
-                const int r = c / CPR;
-                const int gm = m0 + r;
-                float v[VEC];
-                if (gm < M && gk < K) {
-                    V_::load(A + (size_t)gm * p.lda + gk, v);
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) {
+                const int gm = m0 + rbase + i * RSTEP;
+                if (gm < M) {
+                    float v[VEC];
+                    raw_unpack<T>(ra[i], v);
                     if (has_pro) {
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) {
-                            float z = v[i] * sc[i] + sh[i];
-                            v[i] = (p.pro_act == MIA_ACT_SILU) ? siluf_(z) : z;
+                        for (int e = 0; e < VEC; ++e) {
+                            const float z = v[e] * sc[e] + sh[e];
+                            v[e] = (p.pro_act == MIA_ACT_SILU) ? siluf_(z) : z;
                         }
                     }
                     if (has_gate) {
                         const float* g = p.gate + (size_t)(gm / p.rows_per_img) * K + gk;
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) v[i] *= g[i];
+                        for (int e = 0; e < VEC; ++e) v[e] *= g[e];
                     }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) v[i] = 0.f;
+                    ra[i] = raw_pack<T>(v);
                 }
-                V_::store(As + r * LDK + kc, v);
             }
-            // ---- stage B ----
-            for (int c = tid; c < BN * CPR; c += 256) {
-                const int r = c / CPR;
-                const int gn = n0 + r;
-                float v[VEC];
-                if (gn < N && gk < K) {
-                    V_::load(B + (size_t)gn * p.ldb + gk, v);
-                } else {
+        }
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) v[i] = 0.f;
-                }
-                V_::store(Bs + r * LDK + kc, v);
-            }
-            __syncthreads();
+        for (int i = 0; i < ACH; ++i)
+            *reinterpret_cast<raw16*>(As + (rbase + i * RSTEP) * LDK + kc) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BCH; ++i)
+            *reinterpret_cast<raw16*>(Bs + (rbase + i * RSTEP) * LDK + kc) = rb[i];
+    };
+
+    f32x4 acc[MT][NT];
+    int tm = rowslot, k0 = 0;
+    if (tm < tiles_m) prefetch(tm * BM, 0);
+    while (tm < tiles_m) {
+        const int m0 = tm * BM;
+        if (k0 == 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();   // LDS (staging or the C image of the previous tile) is free
+        commit(m0, k0);
+        __syncthreads();
+        // the next stage's global loads fly while this stage's MFMAs (and the epilogue) run
+        int nk0 = k0 + BK, ntm = tm;
+        if (nk0 >= K) { nk0 = 0; ntm = tm + p.row_slots; }
+        if (ntm < tiles_m) prefetch(ntm * BM, nk0);
+        {
             const int krem = (K - k0) < BK ? (K - k0) : BK;
             const int ksteps = (krem + M_::KSTEP - 1) / M_::KSTEP;
             for (int kk = 0; kk < ksteps; ++kk) {
@@ -222,6 +281,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTParams p) {
                     for (int j = 0; j < NT; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]);
             }
         }
+        const bool last_k = (k0 + BK >= K);
+        const int cur_k0 = k0;
+        tm = ntm;
+        k0 = nk0;
+        if (!last_k) continue;
+        (void)cur_k0;
 
         // ---------------------------------- epilogue ----------------------------------
         __syncthreads();  // every wave is done with As/Bs before Cs overwrites them
@@ -302,8 +367,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTParams p) {
         }
     }
     if (p.stats && tid < BN && n0 + tid < N) {
-        p.stats[((size_t)blockIdx.x * 2 + 0) * N + n0 + tid] = st_sum;
-        p.stats[((size_t)blockIdx.x * 2 + 1) * N + n0 + tid] = st_sq;
+        p.stats[((size_t)rowslot * 2 + 0) * N + n0 + tid] = st_sum;
+        p.stats[((size_t)rowslot * 2 + 1) * N + n0 + tid] = st_sq;
     }
 }
 
@@ -317,21 +382,22 @@ static int launch_nt(const GemmNTParams& p, int part_rows, hipStream_t stream) {
     constexpr int MAIN_BYTES = STAGE_BYTES > CS_BYTES ? STAGE_BYTES : CS_BYTES;
     constexpr int LDS_BYTES = MAIN_BYTES + WAVES_M * BN * 2 * (int)sizeof(float);
     const int tiles_m = cdiv(p.M, BM);
-    int gx = p.stats ? part_rows : (tiles_m < 4096 ? tiles_m : 4096);
-    dim3 grid(gx, cdiv(p.N, BN));
+    GemmNTParams q = p;
+    q.row_slots = p.stats ? part_rows : (tiles_m < 1024 ? tiles_m : 1024);
+    dim3 grid((unsigned)(cdiv(q.row_slots, 8) * 8 * cdiv(p.N, BN)));
     auto kern = gemm_nt_kernel<T, BM, BN, WAVES_M, WAVES_N>;
     static bool attr_set = false;
     if (!attr_set && LDS_BYTES > 65536) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, stream, q);
     return 0;
 }
 
 template <typename T>
 static int dispatch_nt(const GemmNTParams& p, int part_rows, hipStream_t stream) {
-    if (p.N <= 32) return launch_nt<T, 256, 32, 4, 1>(p, part_rows, stream);
+    if (p.N <= 32) return launch_nt<T, 128, 32, 4, 1>(p, part_rows, stream);
     if (p.N <= 64) return launch_nt<T, 128, 64, 4, 1>(p, part_rows, stream);
     return launch_nt<T, 128, 128, 2, 2>(p, part_rows, stream);
 }
@@ -419,12 +485,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
     const int cc = (tid % CPR) * VEC;  // column chunk of this thread (same for G and X tiles)
     float sc[VEC], sh[VEC];
     const int gkx = k0 + cc;
-    if (has_pro && gkx < K) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            sc[i] = p.pscale[gkx + i];
-            sh[i] = p.pshift[gkx + i];
-        }
+    for (int i = 0; i < VEC; ++i) {
+        sc[i] = (has_pro && gkx < K) ? p.pscale[gkx + i] : 1.f;
+        sh[i] = (has_pro && gkx < K) ? p.pshift[gkx + i] : 0.f;
     }
 
     const long long chunk_begin = (long long)blockIdx.z * p.chunks_per_split;
@@ -432,43 +496,59 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
     const long long total_chunks = ((long long)M + BR - 1) / BR;
     if (chunk_end > total_chunks) chunk_end = total_chunks;
 
-    for (long long ch = chunk_begin; ch < chunk_end; ++ch) {
+    constexpr int RSTEP = 256 / CPR;
+    constexpr int CH = BR / RSTEP;
+    const int rbase = tid / CPR;
+    raw16 rg[CH], rx[CH];
+    auto prefetch = [&](long long ch) {
         const long long m0 = ch * BR;
-        __syncthreads();
-        for (int c = tid; c < BR * CPR; c += 256) {
-            const int r = c / CPR;
-            const long long gm = m0 + r;
-            float v[VEC];
-            // G tile
-            if (gm < M && n0 + cc < N) {
-                V_::load(G + (size_t)gm * p.ldg + n0 + cc, v);
-            } else {
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) v[i] = 0.f;
-            }
-            V_::store(Gs + r * LD + cc, v);
-            // X tile
-            if (gm < M && gkx < K) {
-                V_::load(X + (size_t)gm * p.ldx + gkx, v);
-                if (has_pro) {
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) {
-                        float z = v[i] * sc[i] + sh[i];
-                        v[i] = (p.pro_act == MIA_ACT_SILU) ? siluf_(z) : z;
-                    }
-                }
-                if (has_gate) {
-                    const float* g = p.gate + (size_t)(gm / p.rows_per_img) * K + gkx;
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) v[i] *= g[i];
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) v[i] = 0.f;
-            }
-            V_::store(Xs + r * LD + cc, v);
+        for (int i = 0; i < CH; ++i) {
+            const long long gm = m0 + rbase + i * RSTEP;
+            rg[i] = make_uint4(0, 0, 0, 0);
+            rx[i] = make_uint4(0, 0, 0, 0);
+            if (gm < M && n0 + cc < N) rg[i] = *reinterpret_cast<const raw16*>(G + (size_t)gm * p.ldg + n0 + cc);
+            if (gm < M && gkx < K) rx[i] = *reinterpret_cast<const raw16*>(X + (size_t)gm * p.ldx + gkx);
         }
+    };
+    auto commit = [&](long long ch) {
+        const long long m0 = ch * BR;
+        if ((has_pro || has_gate) && gkx < K) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const long long gm = m0 + rbase + i * RSTEP;
+                if (gm < M) {
+                    float v[VEC];
+                    raw_unpack<T>(rx[i], v);
+                    if (has_pro) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const float z = v[e] * sc[e] + sh[e];
+                            v[e] = (p.pro_act == MIA_ACT_SILU) ? siluf_(z) : z;
+                        }
+                    }
+                    if (has_gate) {
+                        const float* g = p.gate + (size_t)(gm / p.rows_per_img) * K + gkx;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) v[e] *= g[e];
+                    }
+                    rx[i] = raw_pack<T>(v);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            *reinterpret_cast<raw16*>(Gs + (rbase + i * RSTEP) * LD + cc) = rg[i];
+            *reinterpret_cast<raw16*>(Xs + (rbase + i * RSTEP) * LD + cc) = rx[i];
+        }
+    };
+
+    if (chunk_begin < chunk_end) prefetch(chunk_begin);
+    for (long long ch = chunk_begin; ch < chunk_end; ++ch) {
         __syncthreads();
+        commit(ch);
+        __syncthreads();
+        if (ch + 1 < chunk_end) prefetch(ch + 1);  // in flight during the MFMAs below
         if (mt_cnt > 0 && nt_cnt > 0) {
 #pragma unroll
             for (int kk = 0; kk < BR / M_::KSTEP; ++kk) {

@@ -178,16 +178,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(T* G, const T* Y
         const f4 sc = load4<float>(scale + m.c), sh = load4<float>(shift + m.c);
         const f4 mu = load4<float>(mean + m.c), rs = load4<float>(rstd + m.c);
         const bool writes = (act != MIA_ACT_NONE) || gate || dpool;
-        for (long long r = (long long)blockIdx.x * m.npt + m.pt; r < R; r += (long long)gridDim.x * m.npt) {
-            const size_t idx = (size_t)r * C + m.c;
-            f4 g = load4<T>(G + idx);
-            const f4 y = load4<T>(Y + idx);
+        const long long step = (long long)gridDim.x * m.npt;
+        auto body = [&](long long r, f4 g, const f4 y) {
             if (gate) {
-                const f4 gt = load4<float>(gate + (size_t)(r / rows_per_img) * C + m.c);
+                const f4 gt = load4<float>(gate + (size_t)((unsigned)r / (unsigned)rows_per_img) * C + m.c);
                 g.x *= gt.x; g.y *= gt.y; g.z *= gt.z; g.w *= gt.w;
             }
             if (dpool) {
-                const f4 dp = load4<float>(dpool + (size_t)(r / rows_per_img) * C + m.c);
+                const f4 dp = load4<float>(dpool + (size_t)((unsigned)r / (unsigned)rows_per_img) * C + m.c);
                 g.x += dp.x; g.y += dp.y; g.z += dp.z; g.w += dp.w;
             }
             if (act == MIA_ACT_SILU) {
@@ -201,8 +199,21 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(T* G, const T* Y
             q.y += g.y * ((y.y - mu.y) * rs.y);
             q.z += g.z * ((y.z - mu.z) * rs.z);
             q.w += g.w * ((y.w - mu.w) * rs.w);
-            if (writes) store4<T>(G + idx, g);
+            if (writes) store4<T>(G + (size_t)r * C + m.c, g);
+        };
+        long long r = (long long)blockIdx.x * m.npt + m.pt;
+        // 4 rows per iteration: 8 independent vector loads in flight per lane
+        for (; r + 3 * step < R; r += 4 * step) {
+            f4 g[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u] = load4<T>(G + (size_t)(r + u * step) * C + m.c);
+                y[u] = load4<T>(Y + (size_t)(r + u * step) * C + m.c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) body(r + u * step, g[u], y[u]);
         }
+        for (; r < R; r += step) body(r, load4<T>(G + (size_t)r * C + m.c), load4<T>(Y + (size_t)r * C + m.c));
     }
     block_colsum2(red, m, tid, s, q, part + ((size_t)blockIdx.x * 2 + 0) * C, part + ((size_t)blockIdx.x * 2 + 1) * C);
 }
@@ -215,6 +226,7 @@ extern "C" int mia_bn_act_bwd_reduce(int dtype, void* G, const void* Y, long lon
                   "mia_bn_act_bwd_reduce: bad arguments");
     MIA_CHECK_ARG(part_rows > 0 && part_rows <= 65535, "mia_bn_act_bwd_reduce: bad part_rows");
     MIA_CHECK_ARG(!(gate || dpool) || rows_per_img > 0, "mia_bn_act_bwd_reduce: gate/dpool need rows_per_img");
+    MIA_CHECK_ARG(R < (1LL << 32), "mia_bn_act_bwd_reduce: too many rows");
     int ncb, CB;
     host_colblock(C, &ncb, &CB);
     dim3 grid(part_rows, ncb);
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(256) void affine2_kernel(const T* X, const T* Y, co
                                                       int C, const float* a, const float* b, const float* d, int act) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
         const size_t idx = (size_t)i * 4;
-        const int c = (int)(idx % C);
+        const int c = (int)((unsigned)i % (unsigned)(C >> 2)) << 2;   // 32-bit modulo (host checks the range)
         f4 x = load4<T>(X + idx);
         const f4 av = load4<float>(a + c), dv = load4<float>(d + c);
         f4 o = {x.x * av.x + dv.x, x.y * av.y + dv.y, x.z * av.z + dv.z, x.w * av.w + dv.w};
@@ -267,6 +279,7 @@ extern "C" int mia_affine2(int dtype, const void* X, const void* Y, const void* 
     MIA_CHECK_ARG(X && Out && a && d && R > 0 && C > 0 && C % 4 == 0, "mia_affine2: bad arguments");
     MIA_CHECK_ARG(!Y || b, "mia_affine2: Y needs coefficient b");
     const long long nvec = R * C / 4;
+    MIA_CHECK_ARG(nvec < (1LL << 32), "mia_affine2: tensor too large");
     long long blocks = (nvec + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

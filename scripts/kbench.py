@@ -1,0 +1,100 @@
+"""Micro-benchmark of single kernels at the shapes of the B3 trunk (per-GPU batch 128), for rocprofv3 / tuning.
+usage: python scripts/kbench.py <case> [iters]   cases: dwfwd_s1 dwfwd_s11 dwbwdw_s4 gemm_exp1 gemm_proj1 ..."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import mia_amd
+from mia_amd import ops
+
+def rnd(*s, dtype=torch.bfloat16):
+    return torch.randn(*s, device="cuda").to(dtype)
+
+B = 128
+CASES = {}
+def case(name):
+    def deco(f):
+        CASES[name] = f
+        return f
+    return deco
+
+def dw_case(H, C, k, s, mode):
+    x = rnd(B, H, H, C)
+    w = torch.randn(C, k * k, device="cuda")
+    sc, sh = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1
+    pad = (k - 1) // 2
+    OH = (H + 2 * pad - k) // s + 1
+    dy = rnd(B, OH, OH, C)
+    rows_out = ops.part_rows(B * ((OH * OH + 127) // 128))
+    rows_in = ops.part_rows(B * ((H * H + 127) // 128))
+    if mode == "fwd":
+        nbytes = (x.numel() + dy.numel()) * 2
+        return (lambda: ops.dwconv_fwd(x, w, k, s, pscale=sc, pshift=sh, stats_rows=rows_out)), nbytes
+    if mode == "bwdd":
+        nbytes = (dy.numel() + 2 * x.numel()) * 2
+        return (lambda: ops.dwconv_bwd_data(dy, w, k, s, (H, H), yfwd=x, escale=sc, eshift=sh, emean=sh, erstd=sc, stats_rows=rows_in)), nbytes
+    nbytes = (x.numel() + dy.numel()) * 2
+    return (lambda: ops.dwconv_bwd_weight(x, dy, k, s, pscale=sc, pshift=sh)), nbytes
+
+for mode in ("fwd", "bwdd", "bwdw"):
+    CASES[f"dw{mode}_s1"] = (lambda m=mode: dw_case(75, 192, 3, 1, m))     # stage 1.1
+    CASES[f"dw{mode}_s10"] = (lambda m=mode: dw_case(150, 144, 3, 2, m))   # stage 1.0
+    CASES[f"dw{mode}_s4"] = (lambda m=mode: dw_case(19, 816, 5, 1, m))     # stage 4.x
+    CASES[f"dw{mode}_s5"] = (lambda m=mode: dw_case(10, 1392, 5, 1, m))    # stage 5.x
+    CASES[f"dw{mode}_s2"] = (lambda m=mode: dw_case(38, 288, 5, 1, m))     # stage 2.x
+
+def gemm_case(M, N, K, pro, stats):
+    a, b = rnd(M, K), rnd(N, K)
+    sc, sh = torch.rand(K, device="cuda") + 0.5, torch.randn(K, device="cuda") * 0.1
+    hw = M // B
+    gate = torch.rand(B, K, device="cuda")
+    nbytes = (M * K + N * K + M * N) * 2
+    kw = dict(stats_rows=ops.part_rows((M + 127) // 128) if stats else 0)
+    if pro:
+        kw.update(pscale=sc, pshift=sh, pro_act=ops.ACT_SILU, gate=gate, rows_per_img=hw)
+    return (lambda: ops.gemm_nt(a, b, **kw)), nbytes
+
+CASES["gemm_exp10"] = lambda: gemm_case(B * 150 * 150, 144, 24, False, True)
+CASES["gemm_exp11"] = lambda: gemm_case(B * 75 * 75, 192, 32, False, True)
+CASES["gemm_proj11"] = lambda: gemm_case(B * 75 * 75, 32, 192, True, True)
+CASES["gemm_exp4"] = lambda: gemm_case(B * 19 * 19, 816, 136, False, True)
+CASES["gemm_proj4"] = lambda: gemm_case(B * 19 * 19, 136, 816, True, True)
+CASES["gemm_exp6"] = lambda: gemm_case(B * 100, 2304, 384, False, True)
+CASES["gemm_proj6"] = lambda: gemm_case(B * 100, 384, 2304, True, True)
+CASES["gemm_dz11"] = lambda: gemm_case(B * 75 * 75, 192, 32, False, False)
+
+def tn_case(M, N, K, pro):
+    g, x = rnd(M, N), rnd(M, K)
+    sc, sh = torch.rand(K, device="cuda") + 0.5, torch.randn(K, device="cuda") * 0.1
+    gate = torch.rand(B, K, device="cuda")
+    nbytes = (M * N + M * K) * 2
+    kw = {}
+    if pro:
+        kw.update(pscale=sc, pshift=sh, pro_act=ops.ACT_SILU, gate=gate, rows_per_img=M // B)
+    return (lambda: ops.gemm_tn(g, x, **kw)), nbytes
+
+CASES["tn_exp11"] = lambda: tn_case(B * 75 * 75, 192, 32, False)
+CASES["tn_proj11"] = lambda: tn_case(B * 75 * 75, 32, 192, True)
+CASES["tn_exp4"] = lambda: tn_case(B * 19 * 19, 816, 136, False)
+CASES["tn_proj6"] = lambda: tn_case(B * 100, 384, 2304, True)
+
+def main():
+    names = sys.argv[1].split(",") if len(sys.argv) > 1 else list(CASES)
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    if names == ["all"]:
+        names = list(CASES)
+    for n in names:
+        fn, nbytes = CASES[n]()
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) * 1e3 / iters
+        print(f"{n:14s} {us:9.1f} us  {nbytes / 1e6:9.1f} MB  {nbytes / us / 1e6:8.2f} TB/s", flush=True)
+
+if __name__ == "__main__":
+    main()
