@@ -13,6 +13,7 @@
 //                     both with the fused epilogue g = dA * silu'(z), partials sum(g), sum(g*xhat)
 //   dwconv_bwd_weight dW[c][kh][kw] = sum dY * pro(x)     (per-workgroup partial slab + ordered reduce)
 #include "common.h"
+#include <stdlib.h>
 
 #define DW_PW 4  // output pixels per patch row
 
@@ -408,6 +409,7 @@ static int pick_cb(int C) {
 // dividing evenly over the 256/nvec pixel-threads, within an LDS budget.
 static void pick_tile(int OH, int OW, int K, int S, int CB, int elem, int ph, int extra_out_tile, int lds_budget,
                       int* th, int* tw) {
+    if (const char* e = getenv("MIA_DW_LDS")) lds_budget = atoi(e);  // tuning knob
     static const int ths[] = {2, 4, 6, 8, 10, 12, 16, 20};
     static const int tws[] = {4, 8, 12, 16, 20, 24, 32, 40};
     const int npt = 256 / (CB / 4);

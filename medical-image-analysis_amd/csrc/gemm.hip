@@ -10,6 +10,7 @@
 //
 // Storage type T is float (exact-f32 MFMA 16x16x4) or bf16 (MFMA 16x16x32); accumulation is fp32.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
@@ -139,31 +140,28 @@ struct GemmNTParams {
     int pro_act;
     const float* bias;
     int epi_act;
-    float* stats;  // [row_slots][2][N] or null
+    float* stats;   // [row_slots][2][N] or null
     int row_slots;  // persistent row slots (= partial-sum rows when stats != null)
+    int bk_log2;    // reduction elements per LDS stage (a power of two, at most Mma<T>::BK)
+    int alias_cs;   // 1: the C staging rows reuse the operand stage (one more barrier per tile, less LDS)
 };
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTParams p) {
+// Four waves stacked along M; each wave owns 16*MT complete rows of the BM x BN tile (BM = 64*MT, BN = 16*NT), so
+// the epilogue is wave-local: 16 rows at a time go through a private LDS strip and leave as 16-byte row chunks.
+template <typename T, int MT, int NT, bool PRO>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
     using M_ = Mma<T>;
     using V_ = Vec16<T>;
-    constexpr int BK = M_::BK, LDK = BK + M_::PAD;
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-    constexpr int MT = WM / 16, NT = WN / 16;
+    constexpr int BM = 64 * MT, BN = 16 * NT;
     constexpr int VEC = V_::N;
-    constexpr int CPR = BK / VEC;  // 16-byte chunks per staged row
     constexpr int LDC = BN + VEC;  // C staging row stride (elements)
-    constexpr int STAGE_BYTES = (BM + BN) * LDK * (int)sizeof(T);
-    constexpr int CS_BYTES = BM * LDC * (int)sizeof(T);
-    constexpr int MAIN_BYTES = STAGE_BYTES > CS_BYTES ? STAGE_BYTES : CS_BYTES;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-    static_assert(256 % CPR == 0, "a thread keeps one k-chunk column");
+    constexpr int ACH = BM / 32, BCH = (BN + 31) / 32;  // chunk rows per thread at the deepest stage
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bk = 1 << p.bk_log2, ldk = bk + M_::PAD;
     T* As = reinterpret_cast<T*>(smem);
-    T* Bs = As + BM * LDK;
-    T* Cs = reinterpret_cast<T*>(smem);
-    float* sred = reinterpret_cast<float*>(smem + MAIN_BYTES);  // [WAVES_M][BN][2]
+    T* Bs = As + BM * ldk;
+    const int stage_bytes = (BM + BN) * ldk * (int)sizeof(T);
 
     const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
     const T* __restrict__ B = reinterpret_cast<const T*>(p.B);
@@ -171,7 +169,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTParams p) {
     const T* __restrict__ D = reinterpret_cast<const T*>(p.D);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+    T* Cw = reinterpret_cast<T*>(smem + (p.alias_cs ? 0 : stage_bytes)) + wave * 16 * LDC;
     const int M = p.M, N = p.N, K = p.K;
     // Workgroup -> (row slot, column tile). Blocks b and b+8 share an XCD (and its L2), so the column tiles of
     // one row slot are placed on consecutive slots of ONE XCD: they stream the same A rows at about the same
@@ -181,74 +179,113 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTParams p) {
     const int rowslot = (sidx / ny) * 8 + xcd;
     if (rowslot >= p.row_slots) return;
     const int n0 = (sidx % ny) * BN;
-    const bool has_pro = p.pscale != nullptr;
-    const bool has_gate = p.gate != nullptr;
-    const int kc = (tid % CPR) * VEC;  // this thread's k-chunk offset inside a stage
-    const int rbase = tid / CPR;       // and its first row; further chunks are 256/CPR rows apart
-    constexpr int RSTEP = 256 / CPR;
-    constexpr int ACH = BM / RSTEP, BCH = BN / RSTEP;
+    const bool has_pro = PRO && p.pscale != nullptr;
+    const bool has_gate = PRO && p.gate != nullptr;
+    const int cpr_log2 = p.bk_log2 - (VEC == 8 ? 3 : 2);  // 16-byte chunks per staged row
+    const int kc = (tid & ((1 << cpr_log2) - 1)) * VEC;   // this thread's k-chunk offset inside a stage
+    const int rbase = tid >> cpr_log2;                    // and its first row; further chunks are rstep rows apart
+    const int rstep = 256 >> cpr_log2;
 
-    float st_sum = 0.f, st_sq = 0.f;
+    float st_sum[NT], st_sq[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) st_sum[j] = st_sq[j] = 0.f;
     const int tiles_m = (M + BM - 1) / BM;
 
     raw16 ra[ACH], rb[BCH];
+    float psc[PRO ? VEC : 1], psh[PRO ? VEC : 1];
+    float pg[PRO ? ACH : 1][PRO ? VEC : 1];
+    int img[PRO ? ACH : 1];
+    auto tile_rows = [&](int m0) {
+        if constexpr (PRO) if (has_gate) {
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) {
+                const int gm = m0 + rbase + i * rstep;
+                img[i] = (gm < M ? gm : M - 1) / p.rows_per_img;
+            }
+        }
+    };
     auto prefetch = [&](int m0, int k0) {
         const int gk = k0 + kc;
+        const bool kin = gk < K;
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
-            const int gm = m0 + rbase + i * RSTEP;
+            const int r = rbase + i * rstep, gm = m0 + r;
             ra[i] = make_uint4(0, 0, 0, 0);
-            if (gm < M && gk < K) ra[i] = *reinterpret_cast<const raw16*>(A + (size_t)gm * p.lda + gk);
+            if (r < BM && gm < M && kin) ra[i] = *reinterpret_cast<const raw16*>(A + (size_t)gm * p.lda + gk);
         }
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
-            const int gn = n0 + rbase + i * RSTEP;
+            const int r = rbase + i * rstep, gn = n0 + r;
             rb[i] = make_uint4(0, 0, 0, 0);
-            if (gn < N && gk < K) rb[i] = *reinterpret_cast<const raw16*>(B + (size_t)gn * p.ldb + gk);
+            if (r < BN && gn < N && kin) rb[i] = *reinterpret_cast<const raw16*>(B + (size_t)gn * p.ldb + gk);
+        }
+        if constexpr (PRO) if (has_pro && kin) {
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4) {
+                const float4 a4 = *reinterpret_cast<const float4*>(p.pscale + gk + e);
+                const float4 b4 = *reinterpret_cast<const float4*>(p.pshift + gk + e);
+                psc[e] = a4.x; psc[e + 1] = a4.y; psc[e + 2] = a4.z; psc[e + 3] = a4.w;
+                psh[e] = b4.x; psh[e + 1] = b4.y; psh[e + 2] = b4.z; psh[e + 3] = b4.w;
+            }
+        }
+        if constexpr (PRO) if (has_gate && kin) {
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) {
+                if (rbase + i * rstep < BM) {
+                    const float* g = p.gate + (size_t)img[i] * K + gk;
+#pragma unroll
+                    for (int e = 0; e < VEC; e += 4) {
+                        const float4 g4 = *reinterpret_cast<const float4*>(g + e);
+                        pg[i][e] = g4.x; pg[i][e + 1] = g4.y; pg[i][e + 2] = g4.z; pg[i][e + 3] = g4.w;
+                    }
+                }
+            }
         }
     };
     auto commit = [&](int m0, int k0) {
         const int gk = k0 + kc;
-        if ((has_pro || has_gate) && gk < K) {
-            float sc[VEC], sh[VEC];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                sc[i] = has_pro ? p.pscale[gk + i] : 1.f;
-                sh[i] = has_pro ? p.pshift[gk + i] : 0.f;
-            }
+        if constexpr (PRO) if ((has_pro || has_gate) && gk < K) {
 #pragma unroll
             for (int i = 0; i < ACH; ++i) {
-                const int gm = m0 + rbase + i * RSTEP;
-                if (gm < M) {
+                const int r = rbase + i * rstep, gm = m0 + r;
+                if (r < BM && gm < M) {
                     float v[VEC];
                     raw_unpack<T>(ra[i], v);
                     if (has_pro) {
 #pragma unroll
                         for (int e = 0; e < VEC; ++e) {
-                            const float z = v[e] * sc[e] + sh[e];
+                            const float z = v[e] * psc[e] + psh[e];
                             v[e] = (p.pro_act == MIA_ACT_SILU) ? siluf_(z) : z;
                         }
                     }
                     if (has_gate) {
-                        const float* g = p.gate + (size_t)(gm / p.rows_per_img) * K + gk;
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) v[e] *= g[e];
+                        for (int e = 0; e < VEC; ++e) v[e] *= pg[i][e];
                     }
                     ra[i] = raw_pack<T>(v);
                 }
             }
         }
 #pragma unroll
-        for (int i = 0; i < ACH; ++i)
-            *reinterpret_cast<raw16*>(As + (rbase + i * RSTEP) * LDK + kc) = ra[i];
+        for (int i = 0; i < ACH; ++i) {
+            const int r = rbase + i * rstep;
+            if (r < BM) *reinterpret_cast<raw16*>(As + r * ldk + kc) = ra[i];
+        }
 #pragma unroll
-        for (int i = 0; i < BCH; ++i)
-            *reinterpret_cast<raw16*>(Bs + (rbase + i * RSTEP) * LDK + kc) = rb[i];
+        for (int i = 0; i < BCH; ++i) {
+            const int r = rbase + i * rstep;
+            if (r < BN) *reinterpret_cast<raw16*>(Bs + r * ldk + kc) = rb[i];
+        }
     };
 
     f32x4 acc[MT][NT];
     int tm = rowslot, k0 = 0;
-    if (tm < tiles_m) prefetch(tm * BM, 0);
+    if (tm < tiles_m) {
+        tile_rows(tm * BM);
+        prefetch(tm * BM, 0);
+    }
+    const T* a_frag = As + (wave * 16 * MT + (lane & 15)) * ldk;
+    const T* b_frag = Bs + (lane & 15) * ldk;
     while (tm < tiles_m) {
         const int m0 = tm * BM;
         if (k0 == 0) {
@@ -257,149 +294,198 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTParams p) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        __syncthreads();   // LDS (staging or the C image of the previous tile) is free
+        __syncthreads();  // the operand stage is free (every wave is past its MFMAs and, if aliased, its epilogue)
         commit(m0, k0);
         __syncthreads();
         // the next stage's global loads fly while this stage's MFMAs (and the epilogue) run
-        int nk0 = k0 + BK, ntm = tm;
-        if (nk0 >= K) { nk0 = 0; ntm = tm + p.row_slots; }
+        int nk0 = k0 + bk, ntm = tm;
+        if (nk0 >= K) {
+            nk0 = 0;
+            ntm = tm + p.row_slots;
+            if (ntm < tiles_m) tile_rows(ntm * BM);
+        }
         if (ntm < tiles_m) prefetch(ntm * BM, nk0);
         {
-            const int krem = (K - k0) < BK ? (K - k0) : BK;
+            const int krem = (K - k0) < bk ? (K - k0) : bk;
             const int ksteps = (krem + M_::KSTEP - 1) / M_::KSTEP;
             for (int kk = 0; kk < ksteps; ++kk) {
-                typename M_::Frag a[MT], b[NT];
+                typename M_::Frag a[MT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    a[i] = M_::load(As + (wr * WM + i * 16 + (lane & 15)) * LDK + kk * M_::KSTEP, lane);
+                for (int i = 0; i < MT; ++i) a[i] = M_::load(a_frag + i * 16 * ldk + kk * M_::KSTEP, lane);
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    b[j] = M_::load(Bs + (wc * WN + j * 16 + (lane & 15)) * LDK + kk * M_::KSTEP, lane);
+                for (int j = 0; j < NT; ++j) {
+                    const typename M_::Frag b = M_::load(b_frag + j * 16 * ldk + kk * M_::KSTEP, lane);
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]);
+                    for (int i = 0; i < MT; ++i) acc[i][j] = M_::mma(a[i], b, acc[i][j]);
+                }
             }
         }
-        const bool last_k = (k0 + BK >= K);
-        const int cur_k0 = k0;
+        const bool last_k = (k0 + bk >= K);
         tm = ntm;
         k0 = nk0;
         if (!last_k) continue;
-        (void)cur_k0;
 
-        // ---------------------------------- epilogue ----------------------------------
-        __syncthreads();  // every wave is done with As/Bs before Cs overwrites them
+        // ---------------------------------- epilogue (wave-local) ----------------------------------
+        if (p.alias_cs) __syncthreads();  // every wave is done with As/Bs before the strips overwrite them
         const int lrow = (lane >> 4) * 4, lcol = lane & 15;
         if (p.stats) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                float s = 0.f, q = 0.f;
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float v = acc[i][j][r];
-                        s += v;
-                        q += v * v;
+                        const float v = acc[i][j][r];  // rows past M hold exact zeros (zero-filled A rows)
+                        st_sum[j] += v;
+                        st_sq[j] += v * v;
                     }
-                s += __shfl_xor(s, 16, 64);
-                q += __shfl_xor(q, 16, 64);
-                s += __shfl_xor(s, 32, 64);
-                q += __shfl_xor(q, 32, 64);
-                if (lane < 16) {
-                    const int col = wc * WN + j * 16 + lane;
-                    sred[(wr * BN + col) * 2 + 0] = s;
-                    sred[(wr * BN + col) * 2 + 1] = q;
-                }
-            }
         }
+        const bool vec_ok = (N % VEC) == 0 && (p.ldc % VEC) == 0;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = wc * WN + j * 16 + lcol;
-            const int gn = n0 + col;
-            const float bv = (p.bias && gn < N) ? p.bias[gn] : 0.f;
+        for (int i = 0; i < MT; ++i) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int j = 0; j < NT; ++j) {
+                const int gn = n0 + j * 16 + lcol;
+                const float bv = (p.bias && gn < N) ? p.bias[gn] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = acc[i][j][r] + bv;
                     if (p.epi_act == MIA_ACT_RELU) v = fmaxf(v, 0.f);
                     else if (p.epi_act == MIA_ACT_SILU) v = siluf_(v);
-                    Cs[(wr * WM + i * 16 + lrow + r) * LDC + col] = from_f32<T>(v);
+                    Cw[(lrow + r) * LDC + j * 16 + lcol] = from_f32<T>(v);
                 }
-        }
-        __syncthreads();
-        if (p.stats && tid < BN) {
-#pragma unroll
-            for (int w = 0; w < WAVES_M; ++w) {
-                st_sum += sred[(w * BN + tid) * 2 + 0];
-                st_sq += sred[(w * BN + tid) * 2 + 1];
             }
-        }
-        if ((N % VEC) == 0 && (p.ldc % VEC) == 0) {
-            constexpr int CPC = BN / VEC;
-            for (int c = tid; c < BM * CPC; c += 256) {
-                const int r = c / CPC, cc = (c % CPC) * VEC;
-                const int gm = m0 + r, gn = n0 + cc;
-                if (gm < M && gn < N) {
-                    float v[VEC];
-                    V_::load(Cs + r * LDC + cc, v);
-                    if (D) {
-                        float d[VEC];
-                        V_::load(D + (size_t)gm * p.ldc + gn, d);
+            __builtin_amdgcn_wave_barrier();
+            const int mrow = m0 + wave * 16 * MT + i * 16;
+            if (vec_ok) {
+                constexpr int CPC = BN / VEC;
+                for (int c = lane; c < 16 * CPC; c += 64) {
+                    const int r = c / CPC, cc = (c % CPC) * VEC;
+                    const int gm = mrow + r, gn = n0 + cc;
+                    if (gm < M && gn < N) {
+                        float v[VEC];
+                        V_::load(Cw + r * LDC + cc, v);
+                        if (D) {
+                            float d[VEC];
+                            V_::load(D + (size_t)gm * p.ldc + gn, d);
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) v[i] += d[i];
+                            for (int e = 0; e < VEC; ++e) v[e] += d[e];
+                        }
+                        V_::store(C + (size_t)gm * p.ldc + gn, v);
                     }
-                    V_::store(C + (size_t)gm * p.ldc + gn, v);
+                }
+            } else {
+                for (int c = lane; c < 16 * BN; c += 64) {
+                    const int r = c / BN, cc = c % BN;
+                    const int gm = mrow + r, gn = n0 + cc;
+                    if (gm < M && gn < N) {
+                        float v = to_f32<T>(Cw[r * LDC + cc]);
+                        if (D) v += to_f32<T>(D[(size_t)gm * p.ldc + gn]);
+                        C[(size_t)gm * p.ldc + gn] = from_f32<T>(v);
+                    }
                 }
             }
-        } else {
-            for (int c = tid; c < BM * BN; c += 256) {
-                const int r = c / BN, cc = c % BN;
-                const int gm = m0 + r, gn = n0 + cc;
-                if (gm < M && gn < N) {
-                    float v = to_f32<T>(Cs[r * LDC + cc]);
-                    if (D) v += to_f32<T>(D[(size_t)gm * p.ldc + gn]);
-                    C[(size_t)gm * p.ldc + gn] = from_f32<T>(v);
-                }
-            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
-    if (p.stats && tid < BN && n0 + tid < N) {
-        p.stats[((size_t)rowslot * 2 + 0) * N + n0 + tid] = st_sum;
-        p.stats[((size_t)rowslot * 2 + 1) * N + n0 + tid] = st_sq;
+    if (p.stats) {
+        // lanes l, l+16, l+32, l+48 hold the same column: fold them, then fold the four waves through LDS
+        __syncthreads();
+        float* sred = reinterpret_cast<float*>(smem);  // [4][BN][2]
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float s = st_sum[j], q = st_sq[j];
+            s += __shfl_xor(s, 16, 64);
+            q += __shfl_xor(q, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            q += __shfl_xor(q, 32, 64);
+            if (lane < 16) {
+                sred[(wave * BN + j * 16 + lane) * 2 + 0] = s;
+                sred[(wave * BN + j * 16 + lane) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < N) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                s += sred[(w * BN + tid) * 2 + 0];
+                q += sred[(w * BN + tid) * 2 + 1];
+            }
+            p.stats[((size_t)rowslot * 2 + 0) * N + n0 + tid] = s;
+            p.stats[((size_t)rowslot * 2 + 1) * N + n0 + tid] = q;
+        }
     }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+template <typename T, int MT, int NT, bool PRO>
+static int launch_nt_(const GemmNTParams& p, int part_rows, hipStream_t stream);
+
+template <typename T, int MT, int NT>
 static int launch_nt(const GemmNTParams& p, int part_rows, hipStream_t stream) {
+    if (p.pscale || p.gate) return launch_nt_<T, MT, NT, true>(p, part_rows, stream);
+    return launch_nt_<T, MT, NT, false>(p, part_rows, stream);
+}
+
+template <typename T, int MT, int NT, bool PRO>
+static int launch_nt_(const GemmNTParams& p, int part_rows, hipStream_t stream) {
     using M_ = Mma<T>;
-    constexpr int LDK = M_::BK + M_::PAD;
+    constexpr int BM = 64 * MT, BN = 16 * NT;
     constexpr int VEC = Vec16<T>::N;
-    constexpr int STAGE_BYTES = (BM + BN) * LDK * (int)sizeof(T);
-    constexpr int CS_BYTES = BM * (BN + VEC) * (int)sizeof(T);
-    constexpr int MAIN_BYTES = STAGE_BYTES > CS_BYTES ? STAGE_BYTES : CS_BYTES;
-    constexpr int LDS_BYTES = MAIN_BYTES + WAVES_M * BN * 2 * (int)sizeof(float);
-    const int tiles_m = cdiv(p.M, BM);
     GemmNTParams q = p;
+    // stage depth: the smallest power of two covering K, between one MFMA step (at least 16 elements) and BK
+    int bk = M_::BK;
+    while (bk / 2 >= p.K && bk / 2 >= (M_::KSTEP > 16 ? M_::KSTEP : 16)) bk /= 2;
+    q.bk_log2 = 0;
+    while ((1 << q.bk_log2) < bk) ++q.bk_log2;
+    const int stage_bytes = (BM + BN) * (bk + M_::PAD) * (int)sizeof(T);
+    const int strip_bytes = 4 * 16 * (BN + VEC) * (int)sizeof(T);
+    const int red_bytes = 4 * BN * 2 * (int)sizeof(float);
+    // private strips cost LDS: keep them separate only while three workgroups still fit a CU
+    q.alias_cs = (stage_bytes + strip_bytes) * 3 > 160 * 1024 ? 1 : 0;
+    if (const char* e = getenv("MIA_GEMM_ALIAS")) q.alias_cs = atoi(e);
+    int lds = q.alias_cs ? (stage_bytes > strip_bytes ? stage_bytes : strip_bytes) : stage_bytes + strip_bytes;
+    if (lds < red_bytes) lds = red_bytes;
+    const int tiles_m = cdiv(p.M, BM);
     q.row_slots = p.stats ? part_rows : (tiles_m < 1024 ? tiles_m : 1024);
     dim3 grid((unsigned)(cdiv(q.row_slots, 8) * 8 * cdiv(p.N, BN)));
-    auto kern = gemm_nt_kernel<T, BM, BN, WAVES_M, WAVES_N>;
+    auto kern = gemm_nt_kernel<T, MT, NT, PRO>;
     static bool attr_set = false;
-    if (!attr_set && LDS_BYTES > 65536) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, stream, q);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, q);
     return 0;
 }
 
+// Column-tile widths on offer (multiples of 16). 144 = 6*24 divides most EfficientNet-B3 expanded widths.
 template <typename T>
 static int dispatch_nt(const GemmNTParams& p, int part_rows, hipStream_t stream) {
-    if (p.N <= 32) return launch_nt<T, 128, 32, 4, 1>(p, part_rows, stream);
-    if (p.N <= 64) return launch_nt<T, 128, 64, 4, 1>(p, part_rows, stream);
-    return launch_nt<T, 128, 128, 2, 2>(p, part_rows, stream);
+    static const int widths[] = {32, 48, 96, 128, 144, 192, 240};
+    int best = 128;
+    long long best_cost = -1;
+    for (int w : widths) {
+        const long long padded = (long long)cdiv(p.N, w) * w;
+        // wasted columns first, then fewer column tiles (A is streamed once per column tile)
+        const long long cost = padded * 64 + cdiv(p.N, w);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = w; }
+    }
+    if (const char* e = getenv("MIA_GEMM_BN")) best = atoi(e);
+    // few row tiles: halve the tile height so that the grid still covers the chip
+    const bool small_m = (long long)cdiv(p.M, 128) * cdiv(p.N, best) < 384 && p.M > 64;
+    switch (best) {
+        case 32: return launch_nt<T, 2, 2>(p, part_rows, stream);
+        case 48: return launch_nt<T, 2, 3>(p, part_rows, stream);
+        case 96: return small_m ? launch_nt<T, 1, 6>(p, part_rows, stream) : launch_nt<T, 2, 6>(p, part_rows, stream);
+        case 144: return small_m ? launch_nt<T, 1, 9>(p, part_rows, stream) : launch_nt<T, 2, 9>(p, part_rows, stream);
+        case 192:
+            // 128-row tiles of this width with the prologue's registers would spill
+            return (small_m || p.pscale || p.gate) ? launch_nt<T, 1, 12>(p, part_rows, stream)
+                                                   : launch_nt<T, 2, 12>(p, part_rows, stream);
+        case 240: return launch_nt<T, 1, 15>(p, part_rows, stream);
+        default: return small_m ? launch_nt<T, 1, 8>(p, part_rows, stream) : launch_nt<T, 2, 8>(p, part_rows, stream);
+    }
 }
 
 extern "C" int mia_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* D,
