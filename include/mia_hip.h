@@ -79,6 +79,11 @@ int mia_bn_finalize_bwd(const float* part, int P, int C, double count, const flo
 int mia_bn_act_bwd_reduce(int dtype, void* G, const void* Y, long long R, int C, const float* scale,
                           const float* shift, const float* mean, const float* rstd, int act, const float* gate,
                           const float* dpool, int rows_per_img, float* part, int part_rows, void* stream);
+/* G <- ca*[act'(Y*scale+shift) * (G*gate[b] + dpool[b])] + cb*Y + cd: activation, gate and BatchNorm backward
+ * applied in one pass (gate/dpool optional, b = row / rows_per_img). */
+int mia_bn_act_bwd_apply(int dtype, void* G, const void* Y, long long R, int C, const float* scale, const float* shift,
+                         int act, const float* gate, const float* dpool, int rows_per_img, const float* ca,
+                         const float* cb, const float* cd, void* stream);
 /* Out = act(a[c]*X + b[c]*Y + d[c]) + Res   (Y/b and Res optional; Out may alias X). */
 int mia_affine2(int dtype, const void* X, const void* Y, const void* Res, void* Out, long long R, int C,
                 const float* a, const float* b, const float* d, int act, void* stream);
@@ -95,6 +100,16 @@ int mia_se_gate_fwd(const float* pool_part, int B, int splits, int HW, int C, in
 int mia_se_gate_bwd(const float* dgate_part, int B, int splits, int HW, int C, int RD, const float* Wr,
                     const float* WeT, const float* gate, const float* hpre, const float* pooled, float* dpre2,
                     float* dpre1, float* dpool, float* dWr, float* dbr, float* dWe, float* dbe, void* stream);
+
+/* Backward of a = silu(scale*Y+shift)*gate[b] given dZ = dL/da, in one pass over (Y, dZ): per image and split the
+ * five channel sums  dZ*silu(z) | silu'(z)*dZ | silu'(z)*dZ*xhat | silu'(z) | silu'(z)*xhat  (xhat = (Y-mean)*rstd)
+ * as out [5][B][splits][C]. Plane 0 is the dgate_part of mia_se_gate_bwd; mia_se_bn_combine turns planes 1..4 plus
+ * (gate, dpool) into the partial slab part [B][2][C] of mia_bn_finalize_bwd (timm SqueezeExcite + BatchNormAct2d
+ * backward, done by autograd in the reference). */
+int mia_se_bwd_sums(int dtype, const void* Y, const void* dZ, int B, int HW, int C, const float* scale,
+                    const float* shift, const float* mean, const float* rstd, int splits, float* out, void* stream);
+int mia_se_bn_combine(const float* sums, int B, int splits, int C, const float* gate, const float* dpool, float* part,
+                      void* stream);
 
 /* ---- CBAM (src/model.py:28-108) on an NHWC feature map x [B,H*W,C] -----------------------------------------
  * channel gate (ChannelGate, model.py:45-67): avg/max pool over H*W, shared MLP C->HID->C (ReLU) on both, sum,

@@ -386,11 +386,29 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, cons
 
 // out[i] = sum over rows of slab[row][i]  (fixed order => reproducible)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int rows, long long n, float* out) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float a = 0.f;
-    for (int r = 0; r < rows; ++r) a += slab[(size_t)r * n + i];
-    out[i] = a;
+    // 32 columns x 8 row groups per workgroup: the slab has few columns (C*K*K), so the rows carry the parallelism
+    __shared__ float red[8][32];
+    const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const long long i = (long long)blockIdx.x * 32 + col;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < n) {
+        int r = rg;
+        for (; r + 24 < rows; r += 32) {
+            a0 += slab[(size_t)r * n + i];
+            a1 += slab[(size_t)(r + 8) * n + i];
+            a2 += slab[(size_t)(r + 16) * n + i];
+            a3 += slab[(size_t)(r + 24) * n + i];
+        }
+        for (; r < rows; r += 8) a0 += slab[(size_t)r * n + i];
+    }
+    red[rg][col] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rg == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[g][col];
+        out[i] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -586,7 +604,7 @@ extern "C" int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int
     }
 #undef MIA_DWW
     const long long nout = (long long)C * K * K;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, s, ws, (int)gx, nout, dw);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(nout, 32)), dim3(256), 0, s, ws, (int)gx, nout, dw);
     MIA_CHECK_LAUNCH("mia_dwconv_bwd_weight");
     return 0;
 }

@@ -533,7 +533,7 @@ struct GemmTNParams {
     int chunks_per_split;
 };
 
-template <typename T>
+template <typename T, bool PRO>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
     using M_ = Mma<T>;
     using V_ = Vec16<T>;
@@ -541,12 +541,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
     constexpr int BR = M_::BK;       // reduction rows per stage
     constexpr int VEC = V_::N;
     constexpr int LD = BT + VEC;     // LDS row stride, elements
-    constexpr int CPR = BT / VEC;
+    constexpr int CH = BR * (BT / VEC) / 256;  // 16-byte chunks per thread and operand at full tile width
     constexpr int MT = 4, NT = 4;    // 64x64 per wave
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* Gs = reinterpret_cast<T*>(smem);  // [BR][LD]
     T* Xs = Gs + BR * LD;                // [BR][LD]
+    float* ssm = reinterpret_cast<float*>(Xs + BR * LD);  // [2][BT] prologue scale, shift of this k tile
 
     const T* __restrict__ G = reinterpret_cast<const T*>(p.G);
     const T* __restrict__ X = reinterpret_cast<const T*>(p.X);
@@ -554,8 +555,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
     const int wr = wave >> 1, wc = wave & 1;
     const int n0 = blockIdx.x * BT, k0 = blockIdx.y * BT;
     const int M = p.M, N = p.N, K = p.K;
-    const bool has_pro = p.pscale != nullptr;
-    const bool has_gate = p.gate != nullptr;
+    const bool has_pro = PRO && p.pscale != nullptr;
+    const bool has_gate = PRO && p.gate != nullptr;
 
     // tiles of this wave that hold any valid output
     const int nvalid = N - (n0 + wr * 64), kvalid = K - (k0 + wc * 64);
@@ -568,13 +569,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int cc = (tid % CPR) * VEC;  // column chunk of this thread (same for G and X tiles)
-    float sc[VEC], sh[VEC];
-    const int gkx = k0 + cc;
+    // The (row, 16-byte chunk) items of a stage are dealt to the threads over the VALID width of the tile, so a
+    // narrow operand (24 or 40 channels) still keeps every thread loading and activating.
+    const int cprg = ((N - n0 < BT ? N - n0 : BT) + VEC - 1) / VEC;
+    const int cprx = ((K - k0 < BT ? K - k0 : BT) + VEC - 1) / VEC;
+    int grow[CH], gcol[CH], xrow[CH], xcol[CH];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        sc[i] = (has_pro && gkx < K) ? p.pscale[gkx + i] : 1.f;
-        sh[i] = (has_pro && gkx < K) ? p.pshift[gkx + i] : 0.f;
+    for (int i = 0; i < CH; ++i) {
+        const int idx = tid + i * 256;
+        grow[i] = idx / cprg; gcol[i] = (idx - grow[i] * cprg) * VEC;
+        xrow[i] = idx / cprx; xcol[i] = (idx - xrow[i] * cprx) * VEC;
+    }
+    if (PRO && has_pro && tid < BT) {
+        const bool in = k0 + tid < K;
+        ssm[tid] = in ? p.pscale[k0 + tid] : 1.f;
+        ssm[BT + tid] = in ? p.pshift[k0 + tid] : 0.f;
     }
 
     const long long chunk_begin = (long long)blockIdx.z * p.chunks_per_split;
@@ -582,41 +591,67 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
     const long long total_chunks = ((long long)M + BR - 1) / BR;
     if (chunk_end > total_chunks) chunk_end = total_chunks;
 
-    constexpr int RSTEP = 256 / CPR;
-    constexpr int CH = BR / RSTEP;
-    const int rbase = tid / CPR;
     raw16 rg[CH], rx[CH];
+    float pg[PRO ? CH : 1][PRO ? VEC : 1];
+    // element offsets of this thread's chunks inside a stage (the API bounds operands to < 2^31 elements)
+    unsigned goff[CH], xoff[CH];
+    int ximg[PRO ? CH : 1], xrem[PRO ? CH : 1];  // image index and row-in-image of each X chunk row, kept incrementally
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        goff[i] = (unsigned)(grow[i] * p.ldg + gcol[i]);
+        xoff[i] = (unsigned)(xrow[i] * p.ldx + xcol[i]);
+        if constexpr (PRO) {
+            const long long mf = chunk_begin * BR + xrow[i];
+            ximg[i] = (int)(mf / p.rows_per_img);
+            xrem[i] = (int)(mf - (long long)ximg[i] * p.rows_per_img);
+        }
+    }
+    // chunks are prefetched in increasing order, one call per chunk
     auto prefetch = [&](long long ch) {
-        const long long m0 = ch * BR;
+        const int m0 = (int)(ch * BR);
+        const T* gp = G + (size_t)m0 * p.ldg + n0;
+        const T* xp = X + (size_t)m0 * p.ldx + k0;
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            const long long gm = m0 + rbase + i * RSTEP;
             rg[i] = make_uint4(0, 0, 0, 0);
             rx[i] = make_uint4(0, 0, 0, 0);
-            if (gm < M && n0 + cc < N) rg[i] = *reinterpret_cast<const raw16*>(G + (size_t)gm * p.ldg + n0 + cc);
-            if (gm < M && gkx < K) rx[i] = *reinterpret_cast<const raw16*>(X + (size_t)gm * p.ldx + gkx);
+            if (grow[i] < BR && m0 + grow[i] < M) rg[i] = *reinterpret_cast<const raw16*>(gp + goff[i]);
+            if (xrow[i] < BR && m0 + xrow[i] < M) {
+                rx[i] = *reinterpret_cast<const raw16*>(xp + xoff[i]);
+                if constexpr (PRO) if (has_gate) {
+                    // the gate row rides along with the tile so that its latency is hidden like the tile's
+                    const float* g = p.gate + (unsigned)(ximg[i] * K + k0 + xcol[i]);
+#pragma unroll
+                    for (int e = 0; e < VEC; e += 4) {
+                        const float4 g4 = *reinterpret_cast<const float4*>(g + e);
+                        pg[i][e] = g4.x; pg[i][e + 1] = g4.y; pg[i][e + 2] = g4.z; pg[i][e + 3] = g4.w;
+                    }
+                }
+            }
+            if constexpr (PRO) {
+                xrem[i] += BR;
+                while (xrem[i] >= p.rows_per_img) { xrem[i] -= p.rows_per_img; ++ximg[i]; }
+            }
         }
     };
     auto commit = [&](long long ch) {
         const long long m0 = ch * BR;
-        if ((has_pro || has_gate) && gkx < K) {
+        if constexpr (PRO) if (has_pro || has_gate) {
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
-                const long long gm = m0 + rbase + i * RSTEP;
-                if (gm < M) {
+                if (xrow[i] < BR && m0 + xrow[i] < M) {
                     float v[VEC];
                     raw_unpack<T>(rx[i], v);
                     if (has_pro) {
 #pragma unroll
                         for (int e = 0; e < VEC; ++e) {
-                            const float z = v[e] * sc[e] + sh[e];
+                            const float z = v[e] * ssm[xcol[i] + e] + ssm[BT + xcol[i] + e];
                             v[e] = (p.pro_act == MIA_ACT_SILU) ? siluf_(z) : z;
                         }
                     }
                     if (has_gate) {
-                        const float* g = p.gate + (size_t)(gm / p.rows_per_img) * K + gkx;
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) v[e] *= g[e];
+                        for (int e = 0; e < VEC; ++e) v[e] *= pg[i][e];
                     }
                     rx[i] = raw_pack<T>(v);
                 }
@@ -624,8 +659,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
         }
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            *reinterpret_cast<raw16*>(Gs + (rbase + i * RSTEP) * LD + cc) = rg[i];
-            *reinterpret_cast<raw16*>(Xs + (rbase + i * RSTEP) * LD + cc) = rx[i];
+            if (grow[i] < BR) *reinterpret_cast<raw16*>(Gs + grow[i] * LD + gcol[i]) = rg[i];
+            if (xrow[i] < BR) *reinterpret_cast<raw16*>(Xs + xrow[i] * LD + xcol[i]) = rx[i];
         }
     };
 
@@ -680,6 +715,8 @@ extern "C" int mia_gemm_tn(int dtype, const void* G, int ldg, const void* X, int
     MIA_CHECK_ARG(N % vec == 0 && K % vec == 0 && ldg % vec == 0 && ldx % vec == 0 && ldg >= N && ldx >= K,
                   "mia_gemm_tn: N=%d K=%d ldg=%d ldx=%d must be multiples of %d", N, K, ldg, ldx, vec);
     MIA_CHECK_ARG(ldo >= K, "mia_gemm_tn: ldo=%d < K=%d", ldo, K);
+    MIA_CHECK_ARG((long long)M * ldg < (1ll << 31) && (long long)M * ldx < (1ll << 31),
+                  "mia_gemm_tn: operands must hold fewer than 2^31 elements");
     MIA_CHECK_ARG(((uintptr_t)G % 16) == 0 && ((uintptr_t)X % 16) == 0, "mia_gemm_tn: operands must be 16-byte aligned");
     MIA_CHECK_ARG(!(pscale == nullptr) == !(pshift == nullptr), "mia_gemm_tn: pscale/pshift must come together");
     MIA_CHECK_ARG(!gate || rows_per_img > 0, "mia_gemm_tn: gate needs rows_per_img > 0");
@@ -690,8 +727,10 @@ extern "C" int mia_gemm_tn(int dtype, const void* G, int ldg, const void* X, int
     const int BR = dtype == MIA_BF16 ? 64 : 32;
     const int tiles = cdiv(N, 128) * cdiv(K, 128);
     const long long chunks = ((long long)M + BR - 1) / BR;
-    // aim for ~1536 blocks, at least 4 reduction chunks per block
-    long long splits = 1536 / tiles;
+    // aim for ~512 blocks (two per CU; more splits cost more atomic traffic), at least 4 reduction chunks each
+    long long target_blocks = 512;
+    if (const char* e = getenv("MIA_TN_BLOCKS")) target_blocks = atoi(e);
+    long long splits = target_blocks / tiles;
     if (splits < 1) splits = 1;
     if (splits > (chunks + 3) / 4) splits = (chunks + 3) / 4;
     if (splits < 1) splits = 1;
@@ -699,12 +738,15 @@ extern "C" int mia_gemm_tn(int dtype, const void* G, int ldg, const void* X, int
     splits = (chunks + p.chunks_per_split - 1) / p.chunks_per_split;
     dim3 grid(cdiv(N, 128), cdiv(K, 128), (unsigned)splits);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool pro = pscale || gate;
     if (dtype == MIA_BF16) {
-        constexpr int LDS = 2 * 64 * (128 + 8) * 2;
-        hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, dim3(256), LDS, s, p);
+        constexpr int LDS = 2 * 64 * (128 + 8) * 2 + 2 * 128 * 4;
+        if (pro) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, true>), grid, dim3(256), LDS, s, p);
+        else hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, false>), grid, dim3(256), LDS, s, p);
     } else {
-        constexpr int LDS = 2 * 32 * (128 + 4) * 4;
-        hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), LDS, s, p);
+        constexpr int LDS = 2 * 32 * (128 + 4) * 4 + 2 * 128 * 4;
+        if (pro) hipLaunchKernelGGL((gemm_tn_kernel<float, true>), grid, dim3(256), LDS, s, p);
+        else hipLaunchKernelGGL((gemm_tn_kernel<float, false>), grid, dim3(256), LDS, s, p);
     }
     MIA_CHECK_LAUNCH("mia_gemm_tn");
     return 0;

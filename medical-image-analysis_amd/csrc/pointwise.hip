@@ -367,6 +367,169 @@ extern "C" int mia_img_colsum(int dtype, const void* Y, const void* Wt, int B, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward of  a = silu(z) * gate[b],  z = scale*y + shift  (BatchNorm + SiLU + squeeze-excite), given dZ = dL/da
+// summed over... nothing yet: every per-channel sum the backward needs is a per-image sum of products of dZ, y:
+//   q0 = sum dZ*silu(z)            gradient w.r.t. the gate
+//   q1 = sum silu'(z)*dZ           q2 = sum silu'(z)*dZ*xhat
+//   q3 = sum silu'(z)              q4 = sum silu'(z)*xhat          xhat = (y-mean)*rstd
+// With g = silu'(z)*(dZ*gate[b] + dpool[b]) (the gradient at the BatchNorm output) this gives
+//   sum g = sum_b gate[b]*q1[b] + dpool[b]*q3[b],   sum g*xhat = sum_b gate[b]*q2[b] + dpool[b]*q4[b]
+// so ONE pass over (y, dZ) feeds both the squeeze-excite backward and the BatchNorm backward.
+// out is [5][B][splits][C].
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void se_bwd_sums_kernel(const T* Y, const T* dZ, int B, int HW, int C, int CB,
+                                                          int splits, const float* scale, const float* shift,
+                                                          const float* mean, const float* rstd, float* out) {
+    __shared__ float red[256 * 8];
+    const int tid = threadIdx.x;
+    const RowMap m = make_rowmap(C, CB, blockIdx.y, tid);
+    const int b = blockIdx.x / splits, sp = blockIdx.x % splits;
+    const int rows_per_split = (HW + splits - 1) / splits;
+    const int r_begin = sp * rows_per_split;
+    const int r_end = (r_begin + rows_per_split) < HW ? (r_begin + rows_per_split) : HW;
+    f4 q0 = {0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0, q4 = q0;
+    if (m.valid) {
+        const f4 sc = load4<float>(scale + m.c), sh = load4<float>(shift + m.c);
+        const f4 mu = load4<float>(mean + m.c), rs = load4<float>(rstd + m.c);
+        const T* yb = Y + (size_t)b * HW * C + m.c;
+        const T* wb = dZ + (size_t)b * HW * C + m.c;
+#define SE_ACC(E)                                                       \
+    {                                                                   \
+        const float z = y.E * sc.E + sh.E, sg = sigmoidf_(z);           \
+        const float dsl = sg * (1.0f + z * (1.0f - sg));                \
+        const float xh = (y.E - mu.E) * rs.E, dd = dsl * w.E;           \
+        q0.E += w.E * (z * sg);                                         \
+        q1.E += dd;                                                     \
+        q2.E += dd * xh;                                                \
+        q3.E += dsl;                                                    \
+        q4.E += dsl * xh;                                               \
+    }
+        auto body = [&](const f4 y, const f4 w) { SE_ACC(x) SE_ACC(y) SE_ACC(z) SE_ACC(w) };
+#undef SE_ACC
+        int r = r_begin + m.pt;
+        for (; r + 3 * m.npt < r_end; r += 4 * m.npt) {
+            f4 y[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                y[u] = load4<T>(yb + (size_t)(r + u * m.npt) * C);
+                w[u] = load4<T>(wb + (size_t)(r + u * m.npt) * C);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) body(y[u], w[u]);
+        }
+        for (; r < r_end; r += m.npt) body(load4<T>(yb + (size_t)r * C), load4<T>(wb + (size_t)r * C));
+    }
+    const size_t plane = (size_t)B * splits * C, row = ((size_t)b * splits + sp) * C;
+    block_colsum2(red, m, tid, q0, q1, out + row, out + plane + row);
+    block_colsum2(red, m, tid, q2, q3, out + 2 * plane + row, out + 3 * plane + row);
+    block_colsum2(red, m, tid, q4, q4, out + 4 * plane + row, nullptr);
+}
+
+extern "C" int mia_se_bwd_sums(int dtype, const void* Y, const void* dZ, int B, int HW, int C, const float* scale,
+                               const float* shift, const float* mean, const float* rstd, int splits, float* out,
+                               void* stream) {
+    MIA_CHECK_ARG(Y && dZ && out && scale && shift && mean && rstd && B > 0 && HW > 0 && C > 0 && C % 4 == 0 &&
+                      splits > 0 && splits <= HW,
+                  "mia_se_bwd_sums: bad arguments");
+    const int ncb = cdiv(C, 256);
+    const int CB = cdiv(cdiv(C, 4), ncb) * 4;
+    dim3 grid(B * splits, ncb);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIA_BF16)
+        hipLaunchKernelGGL(se_bwd_sums_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)Y, (const bf16_t*)dZ, B, HW,
+                           C, CB, splits, scale, shift, mean, rstd, out);
+    else
+        hipLaunchKernelGGL(se_bwd_sums_kernel<float>, grid, dim3(256), 0, s, (const float*)Y, (const float*)dZ, B, HW, C,
+                           CB, splits, scale, shift, mean, rstd, out);
+    MIA_CHECK_LAUNCH("mia_se_bwd_sums");
+    return 0;
+}
+
+// per-image rows of the BatchNorm-backward partial slab from the five sums: part [B][2][C]
+__global__ __launch_bounds__(256) void se_bn_combine_kernel(const float* sums, int B, int splits, int C,
+                                                            const float* gate, const float* dpool, float* part) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    const size_t plane = (size_t)B * splits * C;
+    float q[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < splits; ++k) {
+        const size_t o = ((size_t)b * splits + k) * C + c;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q[t] += sums[(t + 1) * plane + o];
+    }
+    const float g = gate[i], dp = dpool[i];
+    part[((size_t)b * 2 + 0) * C + c] = g * q[0] + dp * q[2];
+    part[((size_t)b * 2 + 1) * C + c] = g * q[1] + dp * q[3];
+}
+
+extern "C" int mia_se_bn_combine(const float* sums, int B, int splits, int C, const float* gate, const float* dpool,
+                                 float* part, void* stream) {
+    MIA_CHECK_ARG(sums && gate && dpool && part && B > 0 && splits > 0 && C > 0, "mia_se_bn_combine: bad arguments");
+    hipLaunchKernelGGL(se_bn_combine_kernel, dim3(cdiv((long long)B * C, 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), sums, B, splits, C, gate, dpool, part);
+    MIA_CHECK_LAUNCH("mia_se_bn_combine");
+    return 0;
+}
+
+// dy = ca * [act'(z) * (G*gate[b] + dpool[b])] + cb*y + cd, written over G   (z = scale*y + shift)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(T* G, const T* Y, unsigned nvec, int C,
+                                                               const float* scale, const float* shift, int act,
+                                                               const float* gate, const float* dpool,
+                                                               unsigned vec_per_img, const float* ca, const float* cb,
+                                                               const float* cd) {
+    const unsigned cvec = (unsigned)C >> 2;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < nvec; i += gridDim.x * 256) {
+        const size_t idx = (size_t)i * 4;
+        const int c = (int)(i % cvec) << 2;
+        f4 g = load4<T>(G + idx);
+        const f4 y = load4<T>(Y + idx);
+        if (gate) {
+            const size_t go = (size_t)(i / vec_per_img) * C + c;
+            const f4 gt = load4<float>(gate + go), dp = load4<float>(dpool + go);
+            g.x = g.x * gt.x + dp.x; g.y = g.y * gt.y + dp.y; g.z = g.z * gt.z + dp.z; g.w = g.w * gt.w + dp.w;
+        }
+        if (act == MIA_ACT_SILU) {
+            const f4 sc = load4<float>(scale + c), sh = load4<float>(shift + c);
+            g.x *= silu_gradf_(y.x * sc.x + sh.x);
+            g.y *= silu_gradf_(y.y * sc.y + sh.y);
+            g.z *= silu_gradf_(y.z * sc.z + sh.z);
+            g.w *= silu_gradf_(y.w * sc.w + sh.w);
+        }
+        const f4 a = load4<float>(ca + c), bb = load4<float>(cb + c), d = load4<float>(cd + c);
+        const f4 o = {a.x * g.x + bb.x * y.x + d.x, a.y * g.y + bb.y * y.y + d.y, a.z * g.z + bb.z * y.z + d.z,
+                      a.w * g.w + bb.w * y.w + d.w};
+        store4<T>(G + idx, o);
+    }
+}
+
+extern "C" int mia_bn_act_bwd_apply(int dtype, void* G, const void* Y, long long R, int C, const float* scale,
+                                    const float* shift, int act, const float* gate, const float* dpool,
+                                    int rows_per_img, const float* ca, const float* cb, const float* cd,
+                                    void* stream) {
+    MIA_CHECK_ARG(G && Y && R > 0 && C > 0 && C % 4 == 0 && ca && cb && cd, "mia_bn_act_bwd_apply: bad arguments");
+    MIA_CHECK_ARG(act == MIA_ACT_NONE || (scale && shift), "mia_bn_act_bwd_apply: activation needs scale/shift");
+    MIA_CHECK_ARG(!(gate == nullptr) == !(dpool == nullptr), "mia_bn_act_bwd_apply: gate/dpool must come together");
+    MIA_CHECK_ARG(!gate || rows_per_img > 0, "mia_bn_act_bwd_apply: gate needs rows_per_img");
+    const long long nvec = R * C / 4;
+    MIA_CHECK_ARG(nvec < (1LL << 32), "mia_bn_act_bwd_apply: tensor too large");
+    long long blocks = (nvec + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    const unsigned vpi = (unsigned)((long long)(rows_per_img > 0 ? rows_per_img : 1) * C / 4);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIA_BF16)
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (bf16_t*)G,
+                           (const bf16_t*)Y, (unsigned)nvec, C, scale, shift, act, gate, dpool, vpi, ca, cb, cd);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (float*)G,
+                           (const float*)Y, (unsigned)nvec, C, scale, shift, act, gate, dpool, vpi, ca, cb, cd);
+    MIA_CHECK_LAUNCH("mia_bn_act_bwd_apply");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // squeeze-excite gate: pooled -> FC(rd)+SiLU -> FC(C)+sigmoid.  One workgroup per image.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* pool_part, int splits, float inv_hw, int C,
@@ -402,14 +565,134 @@ __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* pool_part
     }
 }
 
+// ---- wide layers (C*RD large): the two FCs as batched register-tiled products, so that a weight row fetched
+// from L2 serves 8 images and every CU has work (one workgroup per image re-reads both matrices per image).
+constexpr int SE_JT = 4, SE_IB = 8;
+
+// v[b][c] = inv_hw * sum_k part[b][k][c]                         (mode 0, forward pooling)
+// v[b][c] = (sum_k part[b][k][c]) * g[b][c] * (1 - g[b][c])      (mode 1, backward through the sigmoid)
+__global__ __launch_bounds__(256) void se_prep_kernel(const float* part, int splits, float inv_hw, int C, int total,
+                                                      const float* g, int mode, float* v) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int b = i / C, c = i - b * C;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[((size_t)b * splits + k) * C + c];
+    if (mode == 0) v[i] = s * inv_hw;
+    else {
+        const float gv = g[i];
+        v[i] = s * gv * (1.f - gv);
+    }
+}
+
+// d[b][j] = sum_c Wm[j][c] * v[b][c]; one wave per (4 rows j) x (8 images), lanes stride over c.
+// mode 0: pre = d + bias[j] -> out[b][j]                     (forward hidden pre-activation)
+// mode 1: out[b][j] = d * silu'(hpre[b][j])                  (backward through the hidden SiLU)
+__global__ __launch_bounds__(256) void se_reduce_c_kernel(const float* __restrict__ Wm, const float* __restrict__ v,
+                                                          int B, int C, int RD, const float* bias, const float* hpre,
+                                                          int mode, float* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int njt = (RD + SE_JT - 1) / SE_JT;
+    const int wid = blockIdx.x * 4 + wave;
+    const int jt = wid % njt, bt = wid / njt;
+    if (bt * SE_IB >= B) return;
+    const int j0 = jt * SE_JT, b0 = bt * SE_IB;
+    const float* wp[SE_JT];
+    const float* vp[SE_IB];
+#pragma unroll
+    for (int a = 0; a < SE_JT; ++a) wp[a] = Wm + (size_t)(j0 + a < RD ? j0 + a : RD - 1) * C;
+#pragma unroll
+    for (int a = 0; a < SE_IB; ++a) vp[a] = v + (size_t)(b0 + a < B ? b0 + a : B - 1) * C;
+    float acc[SE_JT][SE_IB];
+#pragma unroll
+    for (int a = 0; a < SE_JT; ++a)
+#pragma unroll
+        for (int e = 0; e < SE_IB; ++e) acc[a][e] = 0.f;
+#pragma unroll 2
+    for (int c = lane; c < C; c += 64) {
+        float w[SE_JT], x[SE_IB];
+#pragma unroll
+        for (int a = 0; a < SE_JT; ++a) w[a] = wp[a][c];
+#pragma unroll
+        for (int e = 0; e < SE_IB; ++e) x[e] = vp[e][c];
+#pragma unroll
+        for (int a = 0; a < SE_JT; ++a)
+#pragma unroll
+            for (int e = 0; e < SE_IB; ++e) acc[a][e] += w[a] * x[e];
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int a = 0; a < SE_JT; ++a)
+#pragma unroll
+        for (int e = 0; e < SE_IB; ++e) {
+            const float t = wave_sum(acc[a][e]);
+            if (lane == a * SE_IB + e) mine = t;
+        }
+    if (lane < SE_JT * SE_IB) {
+        const int j = j0 + lane / SE_IB, b = b0 + lane % SE_IB;
+        if (j < RD && b < B) {
+            const size_t o = (size_t)b * RD + j;
+            out[o] = mode == 0 ? mine + bias[j] : mine * silu_gradf_(hpre[o]);
+        }
+    }
+}
+
+// d[b][c] = sum_j Wm[j][c] * act(u[b][j]); one thread per channel and 8 images.
+// mode 0: u = silu(hpre), out = sigmoid(d + bias[c])   (forward gate);  mode 1: u as is, out = d * oscale
+__global__ __launch_bounds__(256) void se_expand_kernel(const float* __restrict__ Wm, const float* __restrict__ u, int B,
+                                                        int C, int RD, const float* bias, float oscale, int mode,
+                                                        float* out) {
+    extern __shared__ float us[];  // [RD][SE_IB]
+    const int c = blockIdx.x * 256 + threadIdx.x, b0 = blockIdx.y * SE_IB;
+    for (int i = threadIdx.x; i < RD * SE_IB; i += 256) {
+        const int j = i / SE_IB, e = i % SE_IB;
+        float t = 0.f;
+        if (b0 + e < B) {
+            t = u[(size_t)(b0 + e) * RD + j];
+            if (mode == 0) t = siluf_(t);
+        }
+        us[i] = t;
+    }
+    __syncthreads();
+    if (c >= C) return;
+    float acc[SE_IB];
+#pragma unroll
+    for (int e = 0; e < SE_IB; ++e) acc[e] = 0.f;
+#pragma unroll 4
+    for (int j = 0; j < RD; ++j) {
+        const float w = Wm[(size_t)j * C + c];
+        const float4 u0 = *reinterpret_cast<const float4*>(us + j * SE_IB);
+        const float4 u1 = *reinterpret_cast<const float4*>(us + j * SE_IB + 4);
+        acc[0] += w * u0.x; acc[1] += w * u0.y; acc[2] += w * u0.z; acc[3] += w * u0.w;
+        acc[4] += w * u1.x; acc[5] += w * u1.y; acc[6] += w * u1.z; acc[7] += w * u1.w;
+    }
+    const float bv = mode == 0 ? bias[c] : 0.f;
+#pragma unroll
+    for (int e = 0; e < SE_IB; ++e)
+        if (b0 + e < B) out[(size_t)(b0 + e) * C + c] = mode == 0 ? sigmoidf_(acc[e] + bv) : acc[e] * oscale;
+}
+
+static inline bool se_wide(int C, int RD) { return (long long)C * RD >= 12000; }
+
 extern "C" int mia_se_gate_fwd(const float* pool_part, int B, int splits, int HW, int C, int RD, const float* Wr,
                                const float* br, const float* WeT, const float* be, float* pooled, float* hpre,
                                float* gate, void* stream) {
     MIA_CHECK_ARG(pool_part && Wr && br && WeT && be && pooled && hpre && gate && B > 0 && C > 0 && RD > 0 && HW > 0,
                   "mia_se_gate_fwd: bad arguments");
-    const size_t lds = (size_t)(C + RD) * 4;
-    hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), pool_part,
-                       splits, 1.0f / (float)HW, C, RD, Wr, br, WeT, be, pooled, hpre, gate);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (se_wide(C, RD)) {
+        hipLaunchKernelGGL(se_prep_kernel, dim3(cdiv((long long)B * C, 256)), dim3(256), 0, s, pool_part, splits,
+                           1.0f / (float)HW, C, B * C, (const float*)nullptr, 0, pooled);
+        const int waves = cdiv(RD, SE_JT) * cdiv(B, SE_IB);
+        hipLaunchKernelGGL(se_reduce_c_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, s, Wr, pooled, B, C, RD, br,
+                           (const float*)nullptr, 0, hpre);
+        hipLaunchKernelGGL(se_expand_kernel, dim3(cdiv(C, 256), cdiv(B, SE_IB)), dim3(256), (size_t)RD * SE_IB * 4, s,
+                           WeT, hpre, B, C, RD, be, 1.f, 0, gate);
+    } else {
+        const size_t lds = (size_t)(C + RD) * 4;
+        hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(256), lds, s, pool_part, splits, 1.0f / (float)HW, C, RD,
+                           Wr, br, WeT, be, pooled, hpre, gate);
+    }
     MIA_CHECK_LAUNCH("mia_se_gate_fwd");
     return 0;
 }
@@ -490,9 +773,19 @@ extern "C" int mia_se_gate_bwd(const float* dgate_part, int B, int splits, int H
                       dbe && B > 0 && C > 0 && RD > 0 && HW > 0,
                   "mia_se_gate_bwd: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const size_t lds = (size_t)(C + RD) * 4;
-    hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(256), lds, s, dgate_part, splits, 1.0f / (float)HW, C, RD, Wr,
-                       WeT, gate, hpre, dpre2, dpre1, dpool);
+    if (se_wide(C, RD)) {
+        hipLaunchKernelGGL(se_prep_kernel, dim3(cdiv((long long)B * C, 256)), dim3(256), 0, s, dgate_part, splits, 0.f,
+                           C, B * C, gate, 1, dpre2);
+        const int waves = cdiv(RD, SE_JT) * cdiv(B, SE_IB);
+        hipLaunchKernelGGL(se_reduce_c_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, s, WeT, dpre2, B, C, RD,
+                           (const float*)nullptr, hpre, 1, dpre1);
+        hipLaunchKernelGGL(se_expand_kernel, dim3(cdiv(C, 256), cdiv(B, SE_IB)), dim3(256), (size_t)RD * SE_IB * 4, s,
+                           Wr, dpre1, B, C, RD, (const float*)nullptr, 1.0f / (float)HW, 1, dpool);
+    } else {
+        const size_t lds = (size_t)(C + RD) * 4;
+        hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(256), lds, s, dgate_part, splits, 1.0f / (float)HW, C, RD,
+                           Wr, WeT, gate, hpre, dpre2, dpre1, dpool);
+    }
     hipLaunchKernelGGL(se_param_grad_kernel, dim3(cdiv((long long)C * RD, 64)), dim3(256), 0, s, B, C, RD, dpre2,
                        dpre1, pooled, hpre, dWr, dbr, dWe, dbe);
     MIA_CHECK_LAUNCH("mia_se_gate_bwd");

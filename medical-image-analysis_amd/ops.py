@@ -199,6 +199,35 @@ def img_colsum(y, wt, scale, shift, act):
     return out
 
 
+def se_bwd_sums(y, dz, stats):
+    """One pass over (y, dz): [5, B, splits, C] per-image sums for the squeeze-excite and BatchNorm backward."""
+    B, H, W, C = y.shape
+    HW = H * W
+    ncb = -(-C // 256)
+    splits = max(1, min(HW // 64, 64, -(-2048 // (B * ncb))))
+    out = torch.empty((5, B, splits, C), dtype=torch.float32, device=y.device)
+    _launch("se_bwd_sums", y.numel() * y.element_size() * 2, lib().mia_se_bwd_sums, _DT[y.dtype], _p(y), _p(dz), B, HW,
+            C, _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), splits, _p(out), _stream())
+    return out
+
+
+def se_bn_combine(sums, gate, dpool):
+    _, B, splits, C = sums.shape
+    part = torch.empty((B, 2, C), dtype=torch.float32, device=sums.device)
+    lib().mia_se_bn_combine(_p(sums), B, splits, C, _p(gate), _p(dpool), _p(part), _stream())
+    return part
+
+
+def bn_act_bwd_apply(g, y, stats, act, coef, *, gate=None, dpool=None, rows_per_img=0):
+    """In place on g: dy = ca*[act'(z)*(g*gate + dpool)] + cb*y + cd."""
+    C = g.shape[-1]
+    R = g.numel() // C
+    _launch("bn_act_bwd_apply", g.numel() * g.element_size() * 3, lib().mia_bn_act_bwd_apply, _DT[g.dtype], _p(g), _p(y),
+            R, C, _p(stats[0]), _p(stats[1]), act, _p(gate), _p(dpool), rows_per_img, _p(coef[2]), _p(coef[3]),
+            _p(coef[4]), _stream())
+    return g
+
+
 def se_gate_fwd(pool_part, hw, wr, br, weT, be):
     B, splits, C = pool_part.shape
     RD = wr.shape[0]
@@ -307,7 +336,7 @@ class MBConvFn(torch.autograd.Function):
         if cfg.kind == "ir":
             M = B * H * W
             wexp, _ = cast_weight(_w2d(w_exp), dt)
-            y1, part = gemm_nt(x.view(M, Cin), wexp, stats_rows=part_rows((M + 127) // 128) if training else 0)
+            y1, part = gemm_nt(x.view(M, Cin), wexp, stats_rows=part_rows((M + 63) // 64) if training else 0)
             st1 = bn_finalize_fwd(part, M, cfg.bn_exp)
             y1 = y1.view(B, H, W, -1)
             dw_in, dw_sc, dw_sh = y1, st1[0], st1[1]
@@ -331,7 +360,7 @@ class MBConvFn(torch.autograd.Function):
         # ---- projection ----
         wproj, _ = cast_weight(_w2d(w_proj), dt)
         y3, part = gemm_nt(y2.view(M2, Cm), wproj, pscale=st2[0], pshift=st2[1], pro_act=ACT_SILU, gate=gate,
-                           rows_per_img=OH * OW, stats_rows=part_rows((M2 + 127) // 128) if training else 0)
+                           rows_per_img=OH * OW, stats_rows=part_rows((M2 + 63) // 64) if training else 0)
         st3 = bn_finalize_fwd(part, M2, cfg.bn_proj)
         Co = y3.shape[1]
         y3 = y3.view(B, OH, OW, Co)
@@ -364,14 +393,13 @@ class MBConvFn(torch.autograd.Function):
         dz, _ = gemm_nt(dy3, wprojT)
         dz = dz.view(B, OH, OW, Cm)
         # ---- squeeze-excite backward ----
-        dgate_part = img_colsum(y2, dz, st2[0], st2[1], ACT_SILU)
+        sums = se_bwd_sums(y2, dz, st2)
         wr = _w2d(w_ser)
         _, weT = cast_weight(_w2d(w_see), torch.float32, want=False, want_t=True)  # [RD, Cm]
-        dpool, dwr, dbr, dwe, dbe = se_gate_bwd(dgate_part, OH * OW, wr, weT, gate, hpre, pooled)
-        # ---- bn after depthwise (+SiLU) ----
-        part = bn_act_bwd_reduce(dz, y2, st2, ACT_SILU, gate=gate, dpool=dpool, rows_per_img=OH * OW)
-        c2 = bn_finalize_bwd(part, M2, g2, st2, training)
-        dy2 = affine2(dz, c2[2], c2[4], y=y2, b=c2[3], out=dz)
+        dpool, dwr, dbr, dwe, dbe = se_gate_bwd(sums[0], OH * OW, wr, weT, gate, hpre, pooled)
+        # ---- bn after depthwise (+SiLU): its reductions come from the same per-image sums ----
+        c2 = bn_finalize_bwd(se_bn_combine(sums, gate, dpool), M2, g2, st2, training)
+        dy2 = bn_act_bwd_apply(dz, y2, st2, ACT_SILU, c2, gate=gate, dpool=dpool, rows_per_img=OH * OW)
         wdw = w_dw.detach().reshape(Cm, k * k)
         rows_in = part_rows(B * ((H * W + 127) // 128))
         if cfg.kind == "ir":

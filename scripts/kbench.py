@@ -48,7 +48,7 @@ def gemm_case(M, N, K, pro, stats):
     hw = M // B
     gate = torch.rand(B, K, device="cuda")
     nbytes = (M * K + N * K + M * N) * 2
-    kw = dict(stats_rows=ops.part_rows((M + 127) // 128) if stats else 0)
+    kw = dict(stats_rows=ops.part_rows((M + 63) // 64) if stats else 0)
     if pro:
         kw.update(pscale=sc, pshift=sh, pro_act=ops.ACT_SILU, gate=gate, rows_per_img=hw)
     return (lambda: ops.gemm_nt(a, b, **kw)), nbytes
@@ -76,6 +76,32 @@ CASES["tn_exp11"] = lambda: tn_case(B * 75 * 75, 192, 32, False)
 CASES["tn_proj11"] = lambda: tn_case(B * 75 * 75, 32, 192, True)
 CASES["tn_exp4"] = lambda: tn_case(B * 19 * 19, 816, 136, False)
 CASES["tn_proj6"] = lambda: tn_case(B * 100, 384, 2304, True)
+CASES["tn_exp5"] = lambda: tn_case(B * 100, 1392, 232, False)
+CASES["tn_proj5"] = lambda: tn_case(B * 100, 232, 1392, True)
+CASES["tn_proj4"] = lambda: tn_case(B * 19 * 19, 136, 816, True)
+CASES["tn_exp6"] = lambda: tn_case(B * 100, 2304, 384, False)
+CASES["tn_proj0"] = lambda: tn_case(B * 150 * 150, 24, 40, True)
+CASES["tn_exp10"] = lambda: tn_case(B * 150 * 150, 144, 24, False)
+CASES["gemm_proj5"] = lambda: gemm_case(B * 100, 232, 1392, True, True)
+CASES["gemm_exp5"] = lambda: gemm_case(B * 100, 1392, 232, False, True)
+CASES["gemm_proj10"] = lambda: gemm_case(B * 75 * 75, 32, 144, True, True)
+
+def se_case(C, RD, hw, mode):
+    part = torch.randn(B, 2, C, device="cuda")
+    wr, br = torch.randn(RD, C, device="cuda") * C ** -0.5, torch.randn(RD, device="cuda") * 0.1
+    weT, be = torch.randn(RD, C, device="cuda") * RD ** -0.5, torch.randn(C, device="cuda") * 0.1
+    pooled, hpre, gate = ops.se_gate_fwd(part, hw, wr, br, weT, be)
+    nbytes = 2 * C * RD * 4 + 3 * B * C * 4
+    if mode == "fwd":
+        return (lambda: ops.se_gate_fwd(part, hw, wr, br, weT, be)), nbytes
+    return (lambda: ops.se_gate_bwd(part, hw, wr, weT, gate, hpre, pooled)), nbytes
+
+for mode in ("fwd", "bwd"):
+    CASES[f"se{mode}_s6"] = (lambda m=mode: se_case(2304, 96, 100, m))
+    CASES[f"se{mode}_s5"] = (lambda m=mode: se_case(1392, 58, 100, m))
+    CASES[f"se{mode}_s4"] = (lambda m=mode: se_case(816, 34, 361, m))
+    CASES[f"se{mode}_s3"] = (lambda m=mode: se_case(576, 24, 361, m))
+    CASES[f"se{mode}_s2"] = (lambda m=mode: se_case(288, 12, 1444, m))
 
 def main():
     names = sys.argv[1].split(",") if len(sys.argv) > 1 else list(CASES)

@@ -241,7 +241,7 @@ def test_affine2_and_img_colsum(dtype):
     assert relerr(ps2.sum(1), (F.silu(x.float() * a + d) * res.float()).sum((1, 2))) < tol(dtype, 1e-5, 1e-3)
 
 
-@pytest.mark.parametrize("C,RD,B,hw", [(144, 6, 4, 100), (2304, 96, 3, 49), (40, 10, 2, 400)])
+@pytest.mark.parametrize("C,RD,B,hw", [(144, 6, 4, 100), (2304, 96, 3, 49), (40, 10, 2, 400), (816, 34, 21, 361), (1392, 58, 16, 100)])
 def test_se_gate_fwd_bwd(C, RD, B, hw):
     pool_part = rnd(B, 3, C, seed=1)
     wr, br = rnd(RD, C, seed=2, scale=C ** -0.5), rnd(RD, seed=3, scale=0.1)
