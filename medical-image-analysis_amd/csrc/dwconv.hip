@@ -38,6 +38,31 @@ __device__ __forceinline__ void fma4(f4& acc, const f4& a, const f4& b) {
     acc.x += a.x * b.x; acc.y += a.y * b.y; acc.z += a.z * b.z; acc.w += a.w * b.w;
 }
 
+// Four channels as two explicit 2-vectors: each 2-vector op is one packed-f32 instruction on a naturally paired
+// register couple. (Left to itself the vectoriser pairs values across taps and spends a move per packed FMA.)
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct f22 {
+    v2f lo, hi;
+};
+template <typename T>
+__device__ __forceinline__ f22 load22(const T* p);
+template <>
+__device__ __forceinline__ f22 load22<float>(const float* p) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    return {v2f{v.x, v.y}, v2f{v.z, v.w}};
+}
+template <>
+__device__ __forceinline__ f22 load22<bf16_t>(const bf16_t* p) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    return {v2f{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u)},
+            v2f{__uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)}};
+}
+__device__ __forceinline__ void fma22(f22& acc, const f22& a, const f22& b) {
+    acc.lo = a.lo * b.lo + acc.lo;
+    acc.hi = a.hi * b.hi + acc.hi;
+}
+__device__ __forceinline__ f4 to_f4(const f22& v) { return {v.lo.x, v.lo.y, v.hi.x, v.hi.y}; }
+
 template <typename T>
 __device__ __forceinline__ void dw_epilogue_store(const DwParams& p, unsigned idx, f4 v, const f4& es, const f4& eh,
                                                   const f4& em, const f4& er, f4& s, f4& q) {
@@ -81,48 +106,95 @@ __device__ __forceinline__ void dw_write_stats(const DwParams& p, float* red, in
     }
 }
 
-// Stage a [rows x cols] pixel window of one image, for this thread's channel vector, into LDS with the optional
-// BatchNorm+SiLU prologue. Thread (pt, cv) walks pixels pt, pt+npt, ... keeping (row, col) incrementally; U
-// independent loads are issued before any is consumed.
-template <typename T, int U>
-__device__ __forceinline__ void dw_stage_tile(const T* __restrict__ img, T* tile, int rows, int cols, int r0, int c0px,
-                                              int H, int W, int C, int cg, bool chan_ok, int cv, int pt, int npt,
-                                              int CB, bool has_pro, const f4& psc, const f4& psh) {
+// Staging of a [rows x cols] pixel window of one image for this thread's channel vector, split in two so that the
+// global loads of the NEXT tile are in flight while the current tile is being computed from LDS:
+//   dw_tile_fetch   issues up to NV vector loads into registers (zero outside the image / channel range)
+//   dw_tile_commit  applies the optional BatchNorm+SiLU prologue and writes the vectors to the LDS tile
+// Thread (pt, cv) walks pixels pt, pt+npt, ... keeping (row, col) incrementally. The host sizes tiles so that a
+// thread owns at most NV pixels.
+template <typename T>
+struct Raw4T;
+template <>
+struct Raw4T<bf16_t> {
+    typedef uint2 type;
+    static __device__ __forceinline__ type zero() { return make_uint2(0, 0); }
+    static __device__ __forceinline__ f4 unpack(type v) {
+        return {__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                __uint_as_float(v.y & 0xffff0000u)};
+    }
+};
+template <>
+struct Raw4T<float> {
+    typedef float4 type;
+    static __device__ __forceinline__ type zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ f4 unpack(type v) { return {v.x, v.y, v.z, v.w}; }
+};
+
+template <typename T, int NV>
+struct TileRegs {
+    typename Raw4T<T>::type v[NV];
+    unsigned inb;  // bit u: v[u] was loaded from inside the image
+};
+
+template <typename T, int NV>
+__device__ __forceinline__ void dw_tile_fetch(TileRegs<T, NV>& t, const T* __restrict__ img, int rows, int cols, int r0,
+                                              int c0px, int H, int W, int C, int cg, bool chan_ok, int pt, int npt) {
+    t.inb = 0u;
     if (pt >= npt) return;
+    // The walk below depends only on (pt, tile shape), not on the tile's position; hiding pt from the optimiser
+    // makes it redo these few adds per tile instead of keeping 3*NV hoisted index registers alive across the
+    // compute phase (which would halve the occupancy).
+    asm volatile("" : "+v"(pt));
     const int npix = rows * cols;
     int pix = pt;
     int row = pt / cols, col = pt - row * cols;   // one division per tile, not per pixel
     const int drow = npt / cols, dcol = npt - drow * cols;
-    while (pix < npix) {
-        f4 v[U];
-        int pixs[U];
-        bool inb[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            pixs[u] = pix;
-            const int ih = r0 + row, iw = c0px + col;
-            inb[u] = pix < npix && chan_ok && ih >= 0 && ih < H && iw >= 0 && iw < W;
-            v[u] = f4{0.f, 0.f, 0.f, 0.f};
-            if (inb[u]) v[u] = load4<T>(img + (unsigned)((ih * W + iw) * C + cg));
-            pix += npt;
-            row += drow;
-            col += dcol;
-            if (col >= cols) { col -= cols; ++row; }
+    for (int u = 0; u < NV; ++u) {
+        const int ih = r0 + row, iw = c0px + col;
+        const bool ok = pix < npix && chan_ok && ih >= 0 && ih < H && iw >= 0 && iw < W;
+        t.v[u] = Raw4T<T>::zero();
+        if (ok) {
+            t.v[u] = *reinterpret_cast<const typename Raw4T<T>::type*>(img + (unsigned)((ih * W + iw) * C + cg));
+            t.inb |= 1u << u;
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (pixs[u] < npix) {
-                if (has_pro && inb[u]) {
-                    v[u].x = siluf_(v[u].x * psc.x + psh.x);
-                    v[u].y = siluf_(v[u].y * psc.y + psh.y);
-                    v[u].z = siluf_(v[u].z * psc.z + psh.z);
-                    v[u].w = siluf_(v[u].w * psc.w + psh.w);
-                }
-                store4<T>(tile + (unsigned)(pixs[u] * CB + cv * 4), v[u]);
-            }
-        }
+        pix += npt;
+        row += drow;
+        col += dcol;
+        if (col >= cols) { col -= cols; ++row; }
     }
 }
+
+template <typename T, int NV>
+__device__ __forceinline__ void dw_tile_commit(const TileRegs<T, NV>& t, T* tile, int npix, int cv, int pt, int npt,
+                                               int CB, bool has_pro, const f4& psc, const f4& psh) {
+    if (pt >= npt) return;
+    asm volatile("" : "+v"(pt));  // as in dw_tile_fetch: recompute the LDS offsets per tile, do not keep them
+    int pix = pt;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        if (pix < npix) {
+            T* dst = tile + (unsigned)(pix * CB + cv * 4);
+            if (has_pro && ((t.inb >> u) & 1u)) {
+                f4 v = Raw4T<T>::unpack(t.v[u]);
+                v.x = siluf_(v.x * psc.x + psh.x);
+                v.y = siluf_(v.y * psc.y + psh.y);
+                v.z = siluf_(v.z * psc.z + psh.z);
+                v.w = siluf_(v.w * psc.w + psh.w);
+                store4<T>(dst, v);
+            } else {
+                *reinterpret_cast<typename Raw4T<T>::type*>(dst) = t.v[u];
+            }
+        }
+        pix += npt;
+        // four vectors at a time: left alone, the scheduler interleaves all NV activations (4*NV live floats)
+        if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+constexpr int DW_NV = 16;   // pixels per thread in a staged input tile (forward / data-gradient kernel)
+constexpr int DW_NVX = 12;  // weight-gradient kernel: input tile
+constexpr int DW_NVD = 8;   //                          output-gradient tile
 
 template <typename T, int K, int S, int PH>
 __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
@@ -167,33 +239,44 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
     const int npatch = patches_h * patches_w;
     const int dph = npt / patches_w, dpw = npt - dph * patches_w;
 
+    TileRegs<T, DW_NV> regs;
+    auto fetch = [&](int work) {
+        const int b = work / tiles_per_img;
+        const int tr = work - b * tiles_per_img;
+        const int trh = tr / p.tiles_w;
+        const int oh0 = trh * TH, ow0 = (tr - trh * p.tiles_w) * TW;
+        dw_tile_fetch<T, DW_NV>(regs, x + (size_t)b * p.H * p.W * p.C, IHT, IWT, oh0 * S - PAD, ow0 * S - PAD, p.H, p.W,
+                                p.C, c, chan_ok, pt, npt);
+    };
+    if ((int)blockIdx.x < total) fetch(blockIdx.x);
     for (int work = blockIdx.x; work < total; work += gridDim.x) {
         const int b = work / tiles_per_img;
         const int tr = work - b * tiles_per_img;
         const int trh = tr / p.tiles_w;
         const int oh0 = trh * TH, ow0 = (tr - trh * p.tiles_w) * TW;
         __syncthreads();  // previous tile fully consumed
-        dw_stage_tile<T, (sizeof(T) == 2 ? 8 : 4)>(x + (size_t)b * p.H * p.W * p.C, tile, IHT, IWT, oh0 * S - PAD,
-                                                    ow0 * S - PAD, p.H, p.W, p.C, c, chan_ok, cv, pt, npt, CB, has_pro,
-                                                    psc, psh);
+        dw_tile_commit<T, DW_NV>(regs, tile, IHT * IWT, cv, pt, npt, CB, has_pro, psc, psh);
         __syncthreads();
+        if (work + (int)gridDim.x < total) fetch(work + gridDim.x);  // in flight while this tile is computed
         if (cvalid) {
-            int ph = pt / patches_w, pw = pt - ph * patches_w;
-            for (int patch = pt; patch < npatch; patch += npt) {
+            int ptc = pt;
+            asm volatile("" : "+v"(ptc));  // patch walk recomputed per tile, not hoisted (registers)
+            int ph = ptc / patches_w, pw = ptc - ph * patches_w;
+            for (int patch = ptc; patch < npatch; patch += npt) {
                 const int ohl = ph * PH, owl = pw * DW_PW;
-                f4 acc[PH][DW_PW];
+                f22 acc[PH][DW_PW];
 #pragma unroll
                 for (int a = 0; a < PH; ++a)
 #pragma unroll
-                    for (int q_ = 0; q_ < DW_PW; ++q_) acc[a][q_] = f4{0.f, 0.f, 0.f, 0.f};
+                    for (int q_ = 0; q_ < DW_PW; ++q_) acc[a][q_] = f22{v2f{0.f, 0.f}, v2f{0.f, 0.f}};
                 // one staged input row at a time (a real loop: keeps the live set to one row + the accumulators);
                 // the row feeds every output row of the patch whose tap row kh = ir - a*S is in range
                 const T* row = tile + (unsigned)(((ohl * S) * IWT + owl * S) * CB + cv * 4);
 #pragma unroll 1
                 for (int ir = 0; ir < NIR; ++ir, row += IWT * CB) {
-                    f4 in[NIN];
+                    f22 in[NIN];
 #pragma unroll
-                    for (int j = 0; j < NIN; ++j) in[j] = load4<T>(row + j * CB);
+                    for (int j = 0; j < NIN; ++j) in[j] = load22<T>(row + j * CB);
 #pragma unroll
                     for (int a = 0; a < PH; ++a) {
                         const int kh = ir - a * S;
@@ -201,9 +284,9 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
                             const float* wrow = wsm + (unsigned)(kh * K * CB + cv * 4);
 #pragma unroll
                             for (int kw = 0; kw < K; ++kw) {
-                                const f4 wv = load4<float>(wrow + kw * CB);
+                                const f22 wv = load22<float>(wrow + kw * CB);
 #pragma unroll
-                                for (int q_ = 0; q_ < DW_PW; ++q_) fma4(acc[a][q_], in[q_ * S + kw], wv);
+                                for (int q_ = 0; q_ < DW_PW; ++q_) fma22(acc[a][q_], in[q_ * S + kw], wv);
                             }
                         }
                     }
@@ -217,7 +300,7 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
                             const int ow = ow0 + owl + q_;
                             if (ow < p.OW) {
                                 const unsigned idx = (unsigned)(((b * p.OH + oh) * p.OW + ow) * p.C + c);
-                                dw_epilogue_store<T>(p, idx, acc[a][q_], es, eh, em, er, st_s, st_q);
+                                dw_epilogue_store<T>(p, idx, to_f4(acc[a][q_]), es, eh, em, er, st_s, st_q);
                             }
                         }
                     }
@@ -322,9 +405,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, cons
     const int cv = tid % nvec, kh = (tid / nvec) % K, pt = tid / nkc;
     const bool cvalid = (cv * 4 < cbv) && (pt < npt);
 
-    f4 acc[K];
+    f22 acc[K];
 #pragma unroll
-    for (int t = 0; t < K; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < K; ++t) acc[t] = f22{v2f{0.f, 0.f}, v2f{0.f, 0.f}};
 
     const int tiles_per_img = p.tiles_h * p.tiles_w;
     const int total = p.B * tiles_per_img;
@@ -332,34 +415,40 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, cons
     const int npatch = TH * patches_w;
     const int dph = npt / patches_w, dpw = npt - dph * patches_w;
 
-    for (int work = blockIdx.x; work < total; work += gridDim.x) {
+    TileRegs<T, DW_NVX> xregs;
+    TileRegs<T, DW_NVD> dregs;
+    auto fetch = [&](int work) {
         const int b = work / tiles_per_img;
         const int tr = work - b * tiles_per_img;
         const int trh = tr / p.tiles_w;
         const int oh0 = trh * TH, ow0 = (tr - trh * p.tiles_w) * TW;
+        dw_tile_fetch<T, DW_NVX>(xregs, x + (size_t)b * p.H * p.W * p.C, IHT, IWT, oh0 * S - PAD, ow0 * S - PAD, p.H,
+                                 p.W, p.C, c0 + s_cv * 4, s_chan_ok, s_pt, s_npt);
+        dw_tile_fetch<T, DW_NVD>(dregs, dy + (size_t)b * p.OH * p.OW * p.C, TH, TW, oh0, ow0, p.OH, p.OW, p.C,
+                                 c0 + s_cv * 4, s_chan_ok, s_pt, s_npt);
+    };
+    if ((int)blockIdx.x < total) fetch(blockIdx.x);
+    for (int work = blockIdx.x; work < total; work += gridDim.x) {
         __syncthreads();
-        dw_stage_tile<T, (sizeof(T) == 2 ? 8 : 4)>(x + (size_t)b * p.H * p.W * p.C, tile, IHT, IWT, oh0 * S - PAD,
-                                                    ow0 * S - PAD, p.H, p.W, p.C, c0 + s_cv * 4, s_chan_ok, s_cv, s_pt,
-                                                    s_npt, CB, has_pro, psc, psh);
-        dw_stage_tile<T, (sizeof(T) == 2 ? 8 : 4)>(dy + (size_t)b * p.OH * p.OW * p.C, dtile, TH, TW, oh0, ow0, p.OH,
-                                                    p.OW, p.C, c0 + s_cv * 4, s_chan_ok, s_cv, s_pt, s_npt, CB, false,
-                                                    one, zero);
+        dw_tile_commit<T, DW_NVX>(xregs, tile, IHT * IWT, s_cv, s_pt, s_npt, CB, has_pro, psc, psh);
+        dw_tile_commit<T, DW_NVD>(dregs, dtile, TH * TW, s_cv, s_pt, s_npt, CB, false, one, zero);
         __syncthreads();
+        if (work + (int)gridDim.x < total) fetch(work + gridDim.x);  // in flight while this tile is reduced
         if (cvalid) {
             int ph = pt / patches_w, pw = pt - ph * patches_w;
             for (int patch = pt; patch < npatch; patch += npt) {
                 const int owl = pw * DW_PW;
                 const T* grow = dtile + (unsigned)((ph * TW + owl) * CB + cv * 4);
                 const T* row = tile + (unsigned)(((ph * S + kh) * IWT + owl * S) * CB + cv * 4);
-                f4 g[DW_PW], in[NIN];
+                f22 g[DW_PW], in[NIN];
 #pragma unroll
-                for (int q_ = 0; q_ < DW_PW; ++q_) g[q_] = load4<T>(grow + q_ * CB);
+                for (int q_ = 0; q_ < DW_PW; ++q_) g[q_] = load22<T>(grow + q_ * CB);
 #pragma unroll
-                for (int j = 0; j < NIN; ++j) in[j] = load4<T>(row + j * CB);
+                for (int j = 0; j < NIN; ++j) in[j] = load22<T>(row + j * CB);
 #pragma unroll
                 for (int kw = 0; kw < K; ++kw)
 #pragma unroll
-                    for (int q_ = 0; q_ < DW_PW; ++q_) fma4(acc[kw], in[q_ * S + kw], g[q_]);
+                    for (int q_ = 0; q_ < DW_PW; ++q_) fma22(acc[kw], in[q_ * S + kw], g[q_]);
                 ph += dph;
                 pw += dpw;
                 if (pw >= patches_w) { pw -= patches_w; ++ph; }
@@ -370,8 +459,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, cons
 #pragma unroll
     for (int kw = 0; kw < K; ++kw) {
         __syncthreads();
-        red[tid * 4 + 0] = acc[kw].x; red[tid * 4 + 1] = acc[kw].y;
-        red[tid * 4 + 2] = acc[kw].z; red[tid * 4 + 3] = acc[kw].w;
+        red[tid * 4 + 0] = acc[kw].lo.x; red[tid * 4 + 1] = acc[kw].lo.y;
+        red[tid * 4 + 2] = acc[kw].hi.x; red[tid * 4 + 3] = acc[kw].hi.y;
         __syncthreads();
         for (int t = tid; t < K * cbv; t += 256) {
             const int khh = t / cbv, ch = t - khh * cbv;
@@ -424,8 +513,9 @@ static int pick_cb(int C) {
 }
 
 // Choose the output tile (TH multiple of ph, TW multiple of 4): few wasted output slots, little halo, patches
-// dividing evenly over the 256/nvec pixel-threads, within an LDS budget.
-static void pick_tile(int OH, int OW, int K, int S, int CB, int elem, int ph, int extra_out_tile, int lds_budget,
+// dividing evenly over the 256/nvec pixel-threads, at most max_in (max_out) staged input (output-gradient) pixels
+// per thread, within an LDS budget.
+static void pick_tile(int OH, int OW, int K, int S, int CB, int elem, int ph, int max_in, int max_out, int lds_budget,
                       int* th, int* tw) {
     if (const char* e = getenv("MIA_DW_LDS")) lds_budget = atoi(e);  // tuning knob
     static const int ths[] = {2, 4, 6, 8, 10, 12, 16, 20};
@@ -437,8 +527,9 @@ static void pick_tile(int OH, int OW, int K, int S, int CB, int elem, int ph, in
         for (int b : tws) {
             if (a % ph) continue;
             const int iht = (a - 1) * S + K, iwt = (b - 1) * S + K;
-            const long long bytes =
-                (long long)iht * iwt * CB * elem + (extra_out_tile ? (long long)a * b * CB * elem : 0);
+            if (cdiv(iht * iwt, npt) > max_in) continue;
+            if (max_out && cdiv(a * b, npt) > max_out) continue;
+            const long long bytes = (long long)iht * iwt * CB * elem + (max_out ? (long long)a * b * CB * elem : 0);
             if (bytes > lds_budget) continue;
             const int nth = cdiv(OH, a), ntw = cdiv(OW, b);
             const double useful = (double)OH * OW;
@@ -492,7 +583,7 @@ extern "C" int mia_dwconv_fwd(int dtype, const void* x, int B, int H, int W, int
     p.pscale = pscale; p.pshift = pshift; p.flip = 0; p.stats = stats;
     p.CB = pick_cb(C);
     const int elem = dtype == MIA_BF16 ? 2 : 4;
-    pick_tile(p.OH, p.OW, K, S, p.CB, elem, tile_ph(S), 0, dtype == MIA_BF16 ? 32768 : 49152, &p.TH, &p.TW);
+    pick_tile(p.OH, p.OW, K, S, p.CB, elem, tile_ph(S), DW_NV, 0, dtype == MIA_BF16 ? 32768 : 65536, &p.TH, &p.TW);
     p.tiles_h = cdiv(p.OH, p.TH); p.tiles_w = cdiv(p.OW, p.TW);
     const int total = B * p.tiles_h * p.tiles_w;
     MIA_CHECK_ARG(!stats || (part_rows > 0 && part_rows <= 65535), "mia_dwconv_fwd: stats needs 0 < part_rows <= 65535");
@@ -530,7 +621,7 @@ extern "C" int mia_dwconv_bwd_data(int dtype, const void* dy, int B, int H, int 
     if (S == 1) {
         // correlation with flipped taps: same tiling kernel, input = dY (OHxOW == HxW), output = dA
         p.x = dy; p.y = dx; p.H = OH; p.W = OW; p.OH = H; p.OW = W; p.flip = 1;
-        pick_tile(p.OH, p.OW, K, 1, p.CB, elem, tile_ph(1), 0, dtype == MIA_BF16 ? 32768 : 49152, &p.TH, &p.TW);
+        pick_tile(p.OH, p.OW, K, 1, p.CB, elem, tile_ph(1), DW_NV, 0, dtype == MIA_BF16 ? 32768 : 65536, &p.TH, &p.TW);
         p.tiles_h = cdiv(p.OH, p.TH); p.tiles_w = cdiv(p.OW, p.TW);
         const int total = B * p.tiles_h * p.tiles_w;
         int gx = total < 8192 ? total : 8192;
@@ -576,7 +667,7 @@ extern "C" int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int
     p.OH = (H + 2 * pad - K) / S + 1; p.OW = (W + 2 * pad - K) / S + 1;
     p.pscale = pscale; p.pshift = pshift; p.CB = pick_cb(C);
     const int elem = dtype == MIA_BF16 ? 2 : 4;
-    pick_tile(p.OH, p.OW, K, S, p.CB, elem, 1, 1, dtype == MIA_BF16 ? 32768 : 49152, &p.TH, &p.TW);
+    pick_tile(p.OH, p.OW, K, S, p.CB, elem, 1, DW_NVX, DW_NVD, dtype == MIA_BF16 ? 40960 : 81920, &p.TH, &p.TW);
     p.tiles_h = cdiv(p.OH, p.TH); p.tiles_w = cdiv(p.OW, p.TW);
     const int total = B * p.tiles_h * p.tiles_w;
     const int ncb = cdiv(C, p.CB);
