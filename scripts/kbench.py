@@ -41,6 +41,8 @@ for mode in ("fwd", "bwdd", "bwdw"):
     CASES[f"dw{mode}_s4"] = (lambda m=mode: dw_case(19, 816, 5, 1, m))     # stage 4.x
     CASES[f"dw{mode}_s5"] = (lambda m=mode: dw_case(10, 1392, 5, 1, m))    # stage 5.x
     CASES[f"dw{mode}_s2"] = (lambda m=mode: dw_case(38, 288, 5, 1, m))     # stage 2.x
+    CASES[f"dw{mode}_s20"] = (lambda m=mode: dw_case(75, 192, 5, 2, m))    # stage 2.0
+    CASES[f"dw{mode}_s30"] = (lambda m=mode: dw_case(38, 288, 3, 2, m))    # stage 3.0
 
 def gemm_case(M, N, K, pro, stats):
     a, b = rnd(M, K), rnd(N, K)

@@ -228,6 +228,42 @@ def test_bn_silu_gate_backward_chain(dtype, C, hw, B):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,hw,B", [(144, 100, 3), (1392, 25, 2), (40, 900, 2), (2304, 100, 5)])
+def test_se_bn_one_pass_backward(dtype, C, hw, B):
+    """se_bwd_sums -> se_bn_combine -> finalize -> bn_act_bwd_apply equals autograd of a = silu(bn(y)) with
+    loss = sum(dZ*a*gate) + sum(dpool*a), and plane 0 of the sums is the gradient w.r.t. the gate."""
+    R = B * hw
+    side = int(round(hw ** 0.5))
+    assert side * side == hw
+    y = rnd(R, C, seed=1, dtype=dtype)
+    dz = rnd(R, C, seed=2, dtype=dtype)
+    gamma, beta = rnd(C, seed=3).abs() + 0.5, rnd(C, seed=4, scale=0.3)
+    gate = torch.sigmoid(rnd(B, C, seed=5))
+    dpool = rnd(B, C, seed=6, scale=0.01)
+    yr = y.float().clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    gater = gate.clone().requires_grad_(True)
+    mean, var = yr.mean(0), yr.var(0, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    a = F.silu((yr - mean) * rstd * gr + br)
+    loss = (dz.float() * a * gater.repeat_interleave(hw, 0)).sum() + (dpool.repeat_interleave(hw, 0) * a).sum()
+    loss.backward()
+    st = torch.stack([gamma * rstd.detach(), beta - mean.detach() * gamma * rstd.detach(), mean.detach(),
+                      rstd.detach()]).contiguous()
+    sums = ops.se_bwd_sums(y.view(B, side, side, C), dz.view(B, side, side, C), st)
+    assert sums.shape[0] == 5 and sums.shape[1] == B and sums.shape[3] == C
+    assert relerr(sums[0].sum(1), gater.grad) < tol(dtype, 5e-5, 3e-2)
+    part = ops.se_bn_combine(sums, gate, dpool)
+    coef = ops.bn_finalize_bwd(part, R, gamma, st, True)
+    g = dz.clone()
+    dy = ops.bn_act_bwd_apply(g, y, st, ops.ACT_SILU, coef, gate=gate, dpool=dpool, rows_per_img=hw)
+    assert dy.data_ptr() == g.data_ptr()
+    assert relerr(dy.float(), yr.grad) < tol(dtype, 5e-5, 3e-2)
+    assert relerr(coef[0], gr.grad) < tol(dtype, 5e-5, 3e-2)
+    assert relerr(coef[1], br.grad) < tol(dtype, 5e-5, 3e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_affine2_and_img_colsum(dtype):
     B, H, W, C = 3, 37, 41, 144
     x, res = rnd(B, H, W, C, seed=1, dtype=dtype), rnd(B, H, W, C, seed=2, dtype=dtype)
