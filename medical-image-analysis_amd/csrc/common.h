@@ -43,6 +43,17 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
     return __builtin_bit_cast(uint16_t, h);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+// two floats -> two bf16 in one dword with ONE v_cvt_pk_bf16_f32 (round to nearest even)
+__device__ __forceinline__ uint32_t pack_bf16x2(v2f v) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 h = __builtin_convertvector(v, bf2);
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ v2f unpack_bf16x2(uint32_t w) {
+    return v2f{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+}
+
 template <typename T>
 __device__ __forceinline__ float to_f32(T x);
 template <>
@@ -88,10 +99,7 @@ __device__ __forceinline__ void store4<float>(float* p, f4 v) {
 }
 template <>
 __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f4 v) {
-    uint2 o;
-    o.x = (uint32_t)f32_to_bf16_bits(v.x) | ((uint32_t)f32_to_bf16_bits(v.y) << 16);
-    o.y = (uint32_t)f32_to_bf16_bits(v.z) | ((uint32_t)f32_to_bf16_bits(v.w) << 16);
-    *reinterpret_cast<uint2*>(p) = o;
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v2f{v.x, v.y}), pack_bf16x2(v2f{v.z, v.w}));
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -99,13 +107,66 @@ __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f4 v) {
 // ----------------------------------------------------------------------------------------------
 // v_exp_f32 + v_rcp_f32 (about 1 ulp each): an IEEE division here would cost ~10 more VALU instructions per
 // element in kernels that are otherwise bandwidth-bound.
-__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
 __device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
 // d/dx silu(x) = s(x) * (1 + x * (1 - s(x)))
 __device__ __forceinline__ float silu_gradf_(float x) {
     float s = sigmoidf_(x);
     return s * (1.0f + x * (1.0f - s));
 }
+
+// ----------------------------------------------------------------------------------------------
+// Two channels at a time. Arithmetic on a 2-vector compiles to the packed-f32 instructions (v_pk_fma_f32,
+// v_pk_mul_f32, v_pk_add_f32: two lanes' worth of work per issue slot); only exp and rcp stay scalar. The
+// activation-heavy kernels are bound by vector-ALU issue, so this halves their cost per element.
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ v2f sigmoid2(v2f z) {
+    const v2f t = z * -1.4426950408889634f;
+    v2f e;
+    e.x = __builtin_amdgcn_exp2f(t.x);
+    e.y = __builtin_amdgcn_exp2f(t.y);
+    const v2f d = e + 1.0f;
+    v2f r;
+    r.x = __builtin_amdgcn_rcpf(d.x);
+    r.y = __builtin_amdgcn_rcpf(d.y);
+    return r;
+}
+__device__ __forceinline__ v2f silu2(v2f z) { return z * sigmoid2(z); }
+__device__ __forceinline__ v2f silu_grad2(v2f z) {
+    const v2f s = sigmoid2(z);
+    return s * (1.0f + z * (1.0f - s));
+}
+// four channels = two 2-vectors
+struct f22 {
+    v2f lo, hi;
+};
+template <typename T>
+__device__ __forceinline__ f22 load22(const T* p);
+template <>
+__device__ __forceinline__ f22 load22<float>(const float* p) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    return {v2f{v.x, v.y}, v2f{v.z, v.w}};
+}
+template <>
+__device__ __forceinline__ f22 load22<bf16_t>(const bf16_t* p) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    return {v2f{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u)},
+            v2f{__uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)}};
+}
+template <typename T>
+__device__ __forceinline__ void store22(T* p, const f22& v);
+template <>
+__device__ __forceinline__ void store22<float>(float* p, const f22& v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v.lo.x, v.lo.y, v.hi.x, v.hi.y);
+}
+template <>
+__device__ __forceinline__ void store22<bf16_t>(bf16_t* p, const f22& v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.lo), pack_bf16x2(v.hi));
+}
+__device__ __forceinline__ f4 to_f4(const f22& v) { return {v.lo.x, v.lo.y, v.hi.x, v.hi.y}; }
+__device__ __forceinline__ f22 to_f22(const f4& v) { return {v2f{v.x, v.y}, v2f{v.z, v.w}}; }
 
 // ----------------------------------------------------------------------------------------------
 // wave (64-lane) reductions via DPP-lowered shuffles

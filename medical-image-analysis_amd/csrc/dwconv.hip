@@ -38,30 +38,12 @@ __device__ __forceinline__ void fma4(f4& acc, const f4& a, const f4& b) {
     acc.x += a.x * b.x; acc.y += a.y * b.y; acc.z += a.z * b.z; acc.w += a.w * b.w;
 }
 
-// Four channels as two explicit 2-vectors: each 2-vector op is one packed-f32 instruction on a naturally paired
-// register couple. (Left to itself the vectoriser pairs values across taps and spends a move per packed FMA.)
-typedef float v2f __attribute__((ext_vector_type(2)));
-struct f22 {
-    v2f lo, hi;
-};
-template <typename T>
-__device__ __forceinline__ f22 load22(const T* p);
-template <>
-__device__ __forceinline__ f22 load22<float>(const float* p) {
-    const float4 v = *reinterpret_cast<const float4*>(p);
-    return {v2f{v.x, v.y}, v2f{v.z, v.w}};
-}
-template <>
-__device__ __forceinline__ f22 load22<bf16_t>(const bf16_t* p) {
-    const uint2 v = *reinterpret_cast<const uint2*>(p);
-    return {v2f{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u)},
-            v2f{__uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)}};
-}
+// Four channels as two explicit 2-vectors (f22): each 2-vector op is one packed-f32 instruction on a naturally
+// paired register couple. (Left to itself the vectoriser pairs values across taps and spends a move per packed FMA.)
 __device__ __forceinline__ void fma22(f22& acc, const f22& a, const f22& b) {
     acc.lo = a.lo * b.lo + acc.lo;
     acc.hi = a.hi * b.hi + acc.hi;
 }
-__device__ __forceinline__ f4 to_f4(const f22& v) { return {v.lo.x, v.lo.y, v.hi.x, v.hi.y}; }
 
 template <typename T>
 __device__ __forceinline__ void dw_epilogue_store(const DwParams& p, unsigned idx, f4 v, const f4& es, const f4& eh,

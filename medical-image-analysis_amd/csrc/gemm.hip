@@ -89,8 +89,7 @@ struct Vec16<bf16_t> {
     static __device__ __forceinline__ void store(bf16_t* p, const float* o) {
         uint32_t w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            w[i] = (uint32_t)f32_to_bf16_bits(o[2 * i]) | ((uint32_t)f32_to_bf16_bits(o[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(v2f{o[2 * i], o[2 * i + 1]});
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
@@ -122,9 +121,59 @@ template <>
 __device__ __forceinline__ raw16 raw_pack<bf16_t>(const float* o) {
     uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        w[i] = (uint32_t)f32_to_bf16_bits(o[2 * i]) | ((uint32_t)f32_to_bf16_bits(o[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(v2f{o[2 * i], o[2 * i + 1]});
     return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// BatchNorm + SiLU (+ gate) on one 16-byte chunk, two channels per instruction.
+// sc/sh/g point at VEC consecutive floats (registers after inlining); g may be null.
+template <typename T>
+struct Pro16;
+template <>
+struct Pro16<bf16_t> {
+    template <bool SILU, bool AFF, bool GATE>
+    static __device__ __forceinline__ raw16 apply(const raw16& r, const float* sc, const float* sh, const float* g) {
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v2f v = unpack_bf16x2(w[i]);
+            if (AFF) v = v * v2f{sc[2 * i], sc[2 * i + 1]} + v2f{sh[2 * i], sh[2 * i + 1]};
+            if (SILU) v = silu2(v);
+            if (GATE) v = v * v2f{g[2 * i], g[2 * i + 1]};
+            o[i] = pack_bf16x2(v);
+        }
+        return make_uint4(o[0], o[1], o[2], o[3]);
+    }
+};
+template <>
+struct Pro16<float> {
+    template <bool SILU, bool AFF, bool GATE>
+    static __device__ __forceinline__ raw16 apply(const raw16& r, const float* sc, const float* sh, const float* g) {
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            v2f v = {__uint_as_float(w[2 * i]), __uint_as_float(w[2 * i + 1])};
+            if (AFF) v = v * v2f{sc[2 * i], sc[2 * i + 1]} + v2f{sh[2 * i], sh[2 * i + 1]};
+            if (SILU) v = silu2(v);
+            if (GATE) v = v * v2f{g[2 * i], g[2 * i + 1]};
+            o[2 * i] = __float_as_uint(v.x);
+            o[2 * i + 1] = __float_as_uint(v.y);
+        }
+        return make_uint4(o[0], o[1], o[2], o[3]);
+    }
+};
+// runtime flags -> one of the specialisations (wave-uniform branches, taken once per chunk)
+template <typename T>
+__device__ __forceinline__ raw16 pro16(const raw16& r, bool silu, bool aff, bool gate, const float* sc, const float* sh,
+                                       const float* g) {
+    if (aff && silu && gate) return Pro16<T>::template apply<true, true, true>(r, sc, sh, g);
+    if (aff && silu) return Pro16<T>::template apply<true, true, false>(r, sc, sh, g);
+    if (aff && gate) return Pro16<T>::template apply<false, true, true>(r, sc, sh, g);
+    if (aff) return Pro16<T>::template apply<false, true, false>(r, sc, sh, g);
+    if (gate) return Pro16<T>::template apply<false, false, true>(r, sc, sh, g);
+    return r;
 }
 
 struct GemmNTParams {
@@ -144,11 +193,40 @@ struct GemmNTParams {
     int row_slots;  // persistent row slots (= partial-sum rows when stats != null)
     int bk_log2;    // reduction elements per LDS stage (a power of two, at most Mma<T>::BK)
     int alias_cs;   // 1: the C staging rows reuse the operand stage (one more barrier per tile, less LDS)
+    int dump_off;   // byte offset of the per-thread 16-byte dump slots
+};
+
+// Guarded 16-byte loads through a buffer descriptor: an offset at or beyond the descriptor's size returns zeros,
+// so out-of-range rows/columns need no branch. Branch-free loads matter twice: no exec-mask juggling, and the
+// compiler can count the loads in flight, which lets a commit wait for ITS stage only (s_waitcnt vmcnt(N), N > 0)
+// while the next stage's loads stay outstanding. A branchy load sequence degrades every wait to vmcnt(0).
+#define MIA_BUF_OOB 0xffffffffu
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+// stream = true: non-temporal hint for tiles read once (keeps them from evicting the weights in L2)
+template <bool STREAM>
+__device__ __forceinline__ raw16 buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, STREAM ? 2 : 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// One pipeline slot: the registers a thread holds for one (tile, k-stage) between its global loads and its commit.
+template <int ACH, int BCH, int VEC, bool PRO>
+struct NtSlot {
+    raw16 ra[ACH], rb[BCH];
+    float psc[PRO ? VEC : 1], psh[PRO ? VEC : 1];   // BatchNorm scale / shift of this thread's k-chunk
+    float pg[PRO ? ACH : 1][PRO ? VEC : 1];         // gate of each chunk row's image
 };
 
 // Four waves stacked along M; each wave owns 16*MT complete rows of the BM x BN tile (BM = 64*MT, BN = 16*NT), so
 // the epilogue is wave-local: 16 rows at a time go through a private LDS strip and leave as 16-byte row chunks.
-template <typename T, int MT, int NT, bool PRO>
+//
+// Pipeline: TWO stages of global loads are in flight per workgroup (slots R0/R1). When a stage is committed to
+// LDS its slot is refilled with the stage after next, so loads overlap the prologue arithmetic of the commit as
+// well as the MFMAs; with one stage in flight the kernel is bound by the load round trip.
+template <typename T, int MT, int NT, bool PRO, int DEPTH>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
     using M_ = Mma<T>;
     using V_ = Vec16<T>;
@@ -156,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
     constexpr int VEC = V_::N;
     constexpr int LDC = BN + VEC;  // C staging row stride (elements)
     constexpr int ACH = BM / 32, BCH = (BN + 31) / 32;  // chunk rows per thread at the deepest stage
+    typedef NtSlot<ACH, BCH, VEC, PRO> Slot;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bk = 1 << p.bk_log2, ldk = bk + M_::PAD;
@@ -170,6 +249,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     T* Cw = reinterpret_cast<T*>(smem + (p.alias_cs ? 0 : stage_bytes)) + wave * 16 * LDC;
+    T* dump = reinterpret_cast<T*>(smem + p.dump_off + tid * 16);
     const int M = p.M, N = p.N, K = p.K;
     // Workgroup -> (row slot, column tile). Blocks b and b+8 share an XCD (and its L2), so the column tiles of
     // one row slot are placed on consecutive slots of ONE XCD: they stream the same A rows at about the same
@@ -181,112 +261,117 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
     const int n0 = (sidx % ny) * BN;
     const bool has_pro = PRO && p.pscale != nullptr;
     const bool has_gate = PRO && p.gate != nullptr;
+    const bool pro_silu = has_pro && p.pro_act == MIA_ACT_SILU;
     const int cpr_log2 = p.bk_log2 - (VEC == 8 ? 3 : 2);  // 16-byte chunks per staged row
     const int kc = (tid & ((1 << cpr_log2) - 1)) * VEC;   // this thread's k-chunk offset inside a stage
     const int rbase = tid >> cpr_log2;                    // and its first row; further chunks are rstep rows apart
     const int rstep = 256 >> cpr_log2;
+    const float inv_rpi = 1.0f / (float)p.rows_per_img;
 
-    float st_sum[NT], st_sq[NT];
+    float st_sum[NT], st_sq[NT], bias_r[NT];   // bias of this lane's columns, read once (no loads in the epilogue)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) st_sum[j] = st_sq[j] = 0.f;
+    for (int j = 0; j < NT; ++j) {
+        st_sum[j] = st_sq[j] = 0.f;
+        const int gn = n0 + j * 16 + (lane & 15);
+        bias_r[j] = (p.bias && gn < N) ? p.bias[gn] : 0.f;
+    }
     const int tiles_m = (M + BM - 1) / BM;
 
-    raw16 ra[ACH], rb[BCH];
-    float psc[PRO ? VEC : 1], psh[PRO ? VEC : 1];
-    float pg[PRO ? ACH : 1][PRO ? VEC : 1];
-    int img[PRO ? ACH : 1];
-    auto tile_rows = [&](int m0) {
-        if constexpr (PRO) if (has_gate) {
-#pragma unroll
-            for (int i = 0; i < ACH; ++i) {
-                const int gm = m0 + rbase + i * rstep;
-                img[i] = (gm < M ? gm : M - 1) / p.rows_per_img;
-            }
-        }
+    // row / rows_per_img without an integer division: float estimate, then one correction step either way
+    // (rows < 2^24 are exact in float; larger row counts take the division)
+    auto image_of = [&](int row) -> int {
+        if (M >= (1 << 24)) return row / p.rows_per_img;
+        int q = (int)((float)row * inv_rpi);
+        const int rem = row - q * p.rows_per_img;
+        if (rem < 0) --q;
+        else if (rem >= p.rows_per_img) ++q;
+        return q;
     };
-    auto prefetch = [&](int m0, int k0) {
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, (unsigned)(((size_t)(M - 1) * p.lda + K) * sizeof(T)));
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B, (unsigned)(((size_t)(N - 1) * p.ldb + K) * sizeof(T)));
+    const __amdgpu_buffer_rsrc_t rsSc = make_rsrc(p.pscale, has_pro ? (unsigned)K * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rsSh = make_rsrc(p.pshift, has_pro ? (unsigned)K * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rsG = make_rsrc(p.gate, has_gate ? (unsigned)(((size_t)(M - 1) / p.rows_per_img + 1) * K * 4) : 0u);
+    auto fetch = [&](Slot& R, int t, int k0) {
+        const int m0 = t * BM;
         const int gk = k0 + kc;
         const bool kin = gk < K;
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             const int r = rbase + i * rstep, gm = m0 + r;
-            ra[i] = make_uint4(0, 0, 0, 0);
-            if (r < BM && gm < M && kin) ra[i] = *reinterpret_cast<const raw16*>(A + (size_t)gm * p.lda + gk);
+            const unsigned off = (r < BM && gm < M && kin) ? (unsigned)(gm * p.lda + gk) * (unsigned)sizeof(T) : MIA_BUF_OOB;
+            // read-once rows get the streaming hint; with several column tiles the siblings re-read them from L2
+            R.ra[i] = ny == 1 ? buf_load16<true>(rsA, off) : buf_load16<false>(rsA, off);
         }
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
             const int r = rbase + i * rstep, gn = n0 + r;
-            rb[i] = make_uint4(0, 0, 0, 0);
-            if (r < BN && gn < N && kin) rb[i] = *reinterpret_cast<const raw16*>(B + (size_t)gn * p.ldb + gk);
+            const unsigned off = (r < BN && gn < N && kin) ? (unsigned)(gn * p.ldb + gk) * (unsigned)sizeof(T) : MIA_BUF_OOB;
+            R.rb[i] = buf_load16<false>(rsB, off);
         }
-        if constexpr (PRO) if (has_pro && kin) {
+        if constexpr (PRO) {
+            const unsigned koff = kin ? (unsigned)gk * 4u : MIA_BUF_OOB;
+            if (has_pro) {
 #pragma unroll
-            for (int e = 0; e < VEC; e += 4) {
-                const float4 a4 = *reinterpret_cast<const float4*>(p.pscale + gk + e);
-                const float4 b4 = *reinterpret_cast<const float4*>(p.pshift + gk + e);
-                psc[e] = a4.x; psc[e + 1] = a4.y; psc[e + 2] = a4.z; psc[e + 3] = a4.w;
-                psh[e] = b4.x; psh[e + 1] = b4.y; psh[e + 2] = b4.z; psh[e + 3] = b4.w;
+                for (int e = 0; e < VEC; e += 4) {
+                    const raw16 a4 = buf_load16<false>(rsSc, koff + e * 4), b4 = buf_load16<false>(rsSh, koff + e * 4);
+                    R.psc[e] = __uint_as_float(a4.x); R.psc[e + 1] = __uint_as_float(a4.y);
+                    R.psc[e + 2] = __uint_as_float(a4.z); R.psc[e + 3] = __uint_as_float(a4.w);
+                    R.psh[e] = __uint_as_float(b4.x); R.psh[e + 1] = __uint_as_float(b4.y);
+                    R.psh[e + 2] = __uint_as_float(b4.z); R.psh[e + 3] = __uint_as_float(b4.w);
+                }
             }
-        }
-        if constexpr (PRO) if (has_gate && kin) {
+            if (has_gate) {
 #pragma unroll
-            for (int i = 0; i < ACH; ++i) {
-                if (rbase + i * rstep < BM) {
-                    const float* g = p.gate + (size_t)img[i] * K + gk;
+                for (int i = 0; i < ACH; ++i) {
+                    const int gm = m0 + rbase + i * rstep;
+                    const unsigned goff = kin ? (unsigned)(image_of(gm < M ? gm : M - 1) * K + gk) * 4u : MIA_BUF_OOB;
 #pragma unroll
                     for (int e = 0; e < VEC; e += 4) {
-                        const float4 g4 = *reinterpret_cast<const float4*>(g + e);
-                        pg[i][e] = g4.x; pg[i][e + 1] = g4.y; pg[i][e + 2] = g4.z; pg[i][e + 3] = g4.w;
+                        const raw16 g4 = buf_load16<false>(rsG, goff + e * 4);
+                        R.pg[i][e] = __uint_as_float(g4.x); R.pg[i][e + 1] = __uint_as_float(g4.y);
+                        R.pg[i][e + 2] = __uint_as_float(g4.z); R.pg[i][e + 3] = __uint_as_float(g4.w);
                     }
                 }
             }
         }
     };
-    auto commit = [&](int m0, int k0) {
+    auto commit = [&](Slot& R, int m0, int k0) {
         const int gk = k0 + kc;
-        if constexpr (PRO) if ((has_pro || has_gate) && gk < K) {
+        if constexpr (PRO) {
+            if ((has_pro || has_gate) && gk < K) {
 #pragma unroll
-            for (int i = 0; i < ACH; ++i) {
-                const int r = rbase + i * rstep, gm = m0 + r;
-                if (r < BM && gm < M) {
-                    float v[VEC];
-                    raw_unpack<T>(ra[i], v);
-                    if (has_pro) {
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) {
-                            const float z = v[e] * psc[e] + psh[e];
-                            v[e] = (p.pro_act == MIA_ACT_SILU) ? siluf_(z) : z;
-                        }
-                    }
-                    if (has_gate) {
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) v[e] *= pg[i][e];
-                    }
-                    ra[i] = raw_pack<T>(v);
+                for (int i = 0; i < ACH; ++i) {
+                    const int r = rbase + i * rstep, gm = m0 + r;
+                    if (r < BM && gm < M) R.ra[i] = pro16<T>(R.ra[i], pro_silu, has_pro, has_gate, R.psc, R.psh, R.pg[i]);
                 }
             }
         }
+        // chunk rows past the tile (short stages, BN not a multiple of the row step) land in a per-thread dump slot:
+        // unconditional stores keep the commit free of branches (see buf_load16)
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             const int r = rbase + i * rstep;
-            if (r < BM) *reinterpret_cast<raw16*>(As + r * ldk + kc) = ra[i];
+            *reinterpret_cast<raw16*>(r < BM ? As + r * ldk + kc : dump) = R.ra[i];
         }
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
             const int r = rbase + i * rstep;
-            if (r < BN) *reinterpret_cast<raw16*>(Bs + r * ldk + kc) = rb[i];
+            *reinterpret_cast<raw16*>(r < BN ? Bs + r * ldk + kc : dump) = R.rb[i];
         }
     };
 
     f32x4 acc[MT][NT];
-    int tm = rowslot, k0 = 0;
-    if (tm < tiles_m) {
-        tile_rows(tm * BM);
-        prefetch(tm * BM, 0);
-    }
+    int tm = rowslot, k0 = 0;      // stage being consumed
+    int f_tm = rowslot, f_k0 = 0;  // next stage to fetch
+    auto advance = [&](int& t, int& k) {
+        k += bk;
+        if (k >= K) { k = 0; t += p.row_slots; }
+    };
     const T* a_frag = As + (wave * 16 * MT + (lane & 15)) * ldk;
     const T* b_frag = Bs + (lane & 15) * ldk;
-    while (tm < tiles_m) {
+
+    auto step = [&](Slot& R) {
         const int m0 = tm * BM;
         if (k0 == 0) {
 #pragma unroll
@@ -295,16 +380,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
                 for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();  // the operand stage is free (every wave is past its MFMAs and, if aliased, its epilogue)
-        commit(m0, k0);
+        commit(R, m0, k0);
         __syncthreads();
-        // the next stage's global loads fly while this stage's MFMAs (and the epilogue) run
-        int nk0 = k0 + bk, ntm = tm;
-        if (nk0 >= K) {
-            nk0 = 0;
-            ntm = tm + p.row_slots;
-            if (ntm < tiles_m) tile_rows(ntm * BM);
+        // refill this slot with the stage after next: its loads fly during the MFMAs, the epilogue and the NEXT commit
+        if (f_tm < tiles_m) {
+            fetch(R, f_tm, f_k0);
+            advance(f_tm, f_k0);
         }
-        if (ntm < tiles_m) prefetch(ntm * BM, nk0);
         {
             const int krem = (K - k0) < bk ? (K - k0) : bk;
             const int ksteps = (krem + M_::KSTEP - 1) / M_::KSTEP;
@@ -321,9 +403,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
             }
         }
         const bool last_k = (k0 + bk >= K);
-        tm = ntm;
-        k0 = nk0;
-        if (!last_k) continue;
+        advance(tm, k0);
+        if (!last_k) return;
 
         // ---------------------------------- epilogue (wave-local) ----------------------------------
         if (p.alias_cs) __syncthreads();  // every wave is done with As/Bs before the strips overwrite them
@@ -345,11 +426,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const int gn = n0 + j * 16 + lcol;
-                const float bv = (p.bias && gn < N) ? p.bias[gn] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = acc[i][j][r] + bv;
+                    float v = acc[i][j][r] + bias_r[j];
                     if (p.epi_act == MIA_ACT_RELU) v = fmaxf(v, 0.f);
                     else if (p.epi_act == MIA_ACT_SILU) v = siluf_(v);
                     Cw[(lrow + r) * LDC + j * 16 + lcol] = from_f32<T>(v);
@@ -387,7 +466,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
             }
             __builtin_amdgcn_wave_barrier();
         }
+    };
+
+    if constexpr (DEPTH == 2) {
+        Slot R0, R1;
+        if (f_tm < tiles_m) { fetch(R0, f_tm, f_k0); advance(f_tm, f_k0); }
+        if (f_tm < tiles_m) { fetch(R1, f_tm, f_k0); advance(f_tm, f_k0); }
+        while (tm < tiles_m) {
+            step(R0);
+            if (tm >= tiles_m) break;
+            step(R1);
+        }
+    } else {
+        Slot R0;
+        if (f_tm < tiles_m) { fetch(R0, f_tm, f_k0); advance(f_tm, f_k0); }
+        while (tm < tiles_m) step(R0);
     }
+
     if (p.stats) {
         // lanes l, l+16, l+32, l+48 hold the same column: fold them, then fold the four waves through LDS
         __syncthreads();
@@ -421,6 +516,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
 template <typename T, int MT, int NT, bool PRO>
 static int launch_nt_(const GemmNTParams& p, int part_rows, hipStream_t stream);
 
+static int nt_stage_depth(int K, int full, int kstep) {
+    // the smallest power of two covering K, between one MFMA step (at least 16 elements) and the full depth
+    int bk = full;
+    while (bk / 2 >= K && bk / 2 >= (kstep > 16 ? kstep : 16)) bk /= 2;
+    return bk;
+}
+
 template <typename T, int MT, int NT>
 static int launch_nt(const GemmNTParams& p, int part_rows, hipStream_t stream) {
     if (p.pscale || p.gate) return launch_nt_<T, MT, NT, true>(p, part_rows, stream);
@@ -433,9 +535,7 @@ static int launch_nt_(const GemmNTParams& p, int part_rows, hipStream_t stream) 
     constexpr int BM = 64 * MT, BN = 16 * NT;
     constexpr int VEC = Vec16<T>::N;
     GemmNTParams q = p;
-    // stage depth: the smallest power of two covering K, between one MFMA step (at least 16 elements) and BK
-    int bk = M_::BK;
-    while (bk / 2 >= p.K && bk / 2 >= (M_::KSTEP > 16 ? M_::KSTEP : 16)) bk /= 2;
+    const int bk = nt_stage_depth(p.K, M_::BK, M_::KSTEP);
     q.bk_log2 = 0;
     while ((1 << q.bk_log2) < bk) ++q.bk_log2;
     const int stage_bytes = (BM + BN) * (bk + M_::PAD) * (int)sizeof(T);
@@ -446,10 +546,14 @@ static int launch_nt_(const GemmNTParams& p, int part_rows, hipStream_t stream) 
     if (const char* e = getenv("MIA_GEMM_ALIAS")) q.alias_cs = atoi(e);
     int lds = q.alias_cs ? (stage_bytes > strip_bytes ? stage_bytes : strip_bytes) : stage_bytes + strip_bytes;
     if (lds < red_bytes) lds = red_bytes;
+    lds = (lds + 15) & ~15;
+    q.dump_off = lds;
+    lds += 256 * 16;
     const int tiles_m = cdiv(p.M, BM);
     q.row_slots = p.stats ? part_rows : (tiles_m < 1024 ? tiles_m : 1024);
     dim3 grid((unsigned)(cdiv(q.row_slots, 8) * 8 * cdiv(p.N, BN)));
-    auto kern = gemm_nt_kernel<T, MT, NT, PRO>;
+    // wide tiles and prologue variants are short of registers: one stage in flight; narrow plain ones stream: two
+    auto kern = gemm_nt_kernel<T, MT, NT, PRO, ((NT <= 6 && !PRO) ? 2 : 1)>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -499,6 +603,9 @@ extern "C" int mia_gemm_nt(int dtype, const void* A, int lda, const void* B, int
     MIA_CHECK_ARG(K % vec == 0 && lda % vec == 0 && ldb % vec == 0 && lda >= K && ldb >= K,
                   "mia_gemm_nt: K=%d lda=%d ldb=%d must be multiples of %d (16-byte rows)", K, lda, ldb, vec);
     MIA_CHECK_ARG(ldc >= N, "mia_gemm_nt: ldc=%d < N=%d", ldc, N);
+    MIA_CHECK_ARG((long long)M * lda * (dtype == MIA_BF16 ? 2 : 4) < (1ll << 32) &&
+                      (long long)N * ldb * (dtype == MIA_BF16 ? 2 : 4) < (1ll << 32),
+                  "mia_gemm_nt: operands must be smaller than 4 GiB (32-bit buffer offsets)");
     MIA_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0 &&
                       ((uintptr_t)D % 16) == 0,
                   "mia_gemm_nt: operands must be 16-byte aligned");
@@ -640,20 +747,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 if (xrow[i] < BR && m0 + xrow[i] < M) {
-                    float v[VEC];
-                    raw_unpack<T>(rx[i], v);
+                    float sc[VEC], sh[VEC];
                     if (has_pro) {
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) {
-                            const float z = v[e] * ssm[xcol[i] + e] + ssm[BT + xcol[i] + e];
-                            v[e] = (p.pro_act == MIA_ACT_SILU) ? siluf_(z) : z;
+                        for (int e = 0; e < VEC; e += 4) {
+                            const float4 a4 = *reinterpret_cast<const float4*>(ssm + xcol[i] + e);
+                            const float4 b4 = *reinterpret_cast<const float4*>(ssm + BT + xcol[i] + e);
+                            sc[e] = a4.x; sc[e + 1] = a4.y; sc[e + 2] = a4.z; sc[e + 3] = a4.w;
+                            sh[e] = b4.x; sh[e + 1] = b4.y; sh[e + 2] = b4.z; sh[e + 3] = b4.w;
                         }
                     }
-                    if (has_gate) {
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) v[e] *= pg[i][e];
-                    }
-                    rx[i] = raw_pack<T>(v);
+                    rx[i] = pro16<T>(rx[i], has_pro && p.pro_act == MIA_ACT_SILU, has_pro, has_gate, sc, sh, pg[i]);
                 }
             }
         }

@@ -44,7 +44,7 @@ for mode in ("fwd", "bwdd", "bwdw"):
     CASES[f"dw{mode}_s20"] = (lambda m=mode: dw_case(75, 192, 5, 2, m))    # stage 2.0
     CASES[f"dw{mode}_s30"] = (lambda m=mode: dw_case(38, 288, 3, 2, m))    # stage 3.0
 
-def gemm_case(M, N, K, pro, stats):
+def gemm_case(M, N, K, pro, stats, act=None, use_gate=True):
     a, b = rnd(M, K), rnd(N, K)
     sc, sh = torch.rand(K, device="cuda") + 0.5, torch.randn(K, device="cuda") * 0.1
     hw = M // B
@@ -52,7 +52,9 @@ def gemm_case(M, N, K, pro, stats):
     nbytes = (M * K + N * K + M * N) * 2
     kw = dict(stats_rows=ops.part_rows((M + 63) // 64) if stats else 0)
     if pro:
-        kw.update(pscale=sc, pshift=sh, pro_act=ops.ACT_SILU, gate=gate, rows_per_img=hw)
+        kw.update(pscale=sc, pshift=sh, pro_act=ops.ACT_SILU if act is None else act, rows_per_img=hw)
+        if use_gate:
+            kw.update(gate=gate)
     return (lambda: ops.gemm_nt(a, b, **kw)), nbytes
 
 CASES["gemm_exp10"] = lambda: gemm_case(B * 150 * 150, 144, 24, False, True)
@@ -62,6 +64,9 @@ CASES["gemm_exp4"] = lambda: gemm_case(B * 19 * 19, 816, 136, False, True)
 CASES["gemm_proj4"] = lambda: gemm_case(B * 19 * 19, 136, 816, True, True)
 CASES["gemm_exp6"] = lambda: gemm_case(B * 100, 2304, 384, False, True)
 CASES["gemm_proj6"] = lambda: gemm_case(B * 100, 384, 2304, True, True)
+CASES["gemm_proj11_noact"] = lambda: gemm_case(B * 75 * 75, 32, 192, True, True, act=ops.ACT_NONE)
+CASES["gemm_proj11_nogate"] = lambda: gemm_case(B * 75 * 75, 32, 192, True, True, use_gate=False)
+CASES["gemm_proj11_plain"] = lambda: gemm_case(B * 75 * 75, 32, 192, False, True)
 CASES["gemm_dz11"] = lambda: gemm_case(B * 75 * 75, 192, 32, False, False)
 
 def tn_case(M, N, K, pro):
