@@ -46,35 +46,31 @@ __device__ __forceinline__ void fma22(f22& acc, const f22& a, const f22& b) {
 }
 
 template <typename T>
-__device__ __forceinline__ void dw_epilogue_store(const DwParams& p, unsigned idx, f4 v, const f4& es, const f4& eh,
-                                                  const f4& em, const f4& er, f4& s, f4& q) {
+__device__ __forceinline__ void dw_epilogue_store(const DwParams& p, unsigned idx, const f22& v, const f22& es,
+                                                  const f22& eh, const f22& em, const f22& er, f22& s, f22& q) {
     T* y = reinterpret_cast<T*>(p.y);
     if (p.yfwd) {
-        const f4 yv = load4<T>(reinterpret_cast<const T*>(p.yfwd) + idx);
-        f4 g;
-        g.x = v.x * silu_gradf_(yv.x * es.x + eh.x);
-        g.y = v.y * silu_gradf_(yv.y * es.y + eh.y);
-        g.z = v.z * silu_gradf_(yv.z * es.z + eh.z);
-        g.w = v.w * silu_gradf_(yv.w * es.w + eh.w);
-        s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
-        q.x += g.x * ((yv.x - em.x) * er.x);
-        q.y += g.y * ((yv.y - em.y) * er.y);
-        q.z += g.z * ((yv.z - em.z) * er.z);
-        q.w += g.w * ((yv.w - em.w) * er.w);
-        store4<T>(y + idx, g);
+        const f22 yv = load22<T>(reinterpret_cast<const T*>(p.yfwd) + idx);
+        f22 g;
+        g.lo = v.lo * silu_grad2(yv.lo * es.lo + eh.lo);
+        g.hi = v.hi * silu_grad2(yv.hi * es.hi + eh.hi);
+        s.lo += g.lo; s.hi += g.hi;
+        q.lo += g.lo * ((yv.lo - em.lo) * er.lo);
+        q.hi += g.hi * ((yv.hi - em.hi) * er.hi);
+        store22<T>(y + idx, g);
     } else {
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
-        store4<T>(y + idx, v);
+        s.lo += v.lo; s.hi += v.hi;
+        q.lo += v.lo * v.lo; q.hi += v.hi * v.hi;
+        store22<T>(y + idx, v);
     }
 }
 
 // block-level reduction of per-thread (s, q) over the pixel-threads that share a channel vector
 __device__ __forceinline__ void dw_write_stats(const DwParams& p, float* red, int tid, int nvec, int npt, int c0,
-                                               int cbv, f4 s, f4 q) {
+                                               int cbv, const f22& s, const f22& q) {
     __syncthreads();
-    red[tid * 8 + 0] = s.x; red[tid * 8 + 1] = s.y; red[tid * 8 + 2] = s.z; red[tid * 8 + 3] = s.w;
-    red[tid * 8 + 4] = q.x; red[tid * 8 + 5] = q.y; red[tid * 8 + 6] = q.z; red[tid * 8 + 7] = q.w;
+    red[tid * 8 + 0] = s.lo.x; red[tid * 8 + 1] = s.lo.y; red[tid * 8 + 2] = s.hi.x; red[tid * 8 + 3] = s.hi.y;
+    red[tid * 8 + 4] = q.lo.x; red[tid * 8 + 5] = q.lo.y; red[tid * 8 + 6] = q.hi.x; red[tid * 8 + 7] = q.hi.y;
     __syncthreads();
     if (tid < cbv) {
         const int cv = tid >> 2, e = tid & 3;
@@ -100,16 +96,13 @@ template <>
 struct Raw4T<bf16_t> {
     typedef uint2 type;
     static __device__ __forceinline__ type zero() { return make_uint2(0, 0); }
-    static __device__ __forceinline__ f4 unpack(type v) {
-        return {__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
-                __uint_as_float(v.y & 0xffff0000u)};
-    }
+    static __device__ __forceinline__ f22 unpack22(type v) { return {unpack_bf16x2(v.x), unpack_bf16x2(v.y)}; }
 };
 template <>
 struct Raw4T<float> {
     typedef float4 type;
     static __device__ __forceinline__ type zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-    static __device__ __forceinline__ f4 unpack(type v) { return {v.x, v.y, v.z, v.w}; }
+    static __device__ __forceinline__ f22 unpack22(type v) { return {v2f{v.x, v.y}, v2f{v.z, v.w}}; }
 };
 
 template <typename T, int NV>
@@ -149,7 +142,7 @@ __device__ __forceinline__ void dw_tile_fetch(TileRegs<T, NV>& t, const T* __res
 
 template <typename T, int NV>
 __device__ __forceinline__ void dw_tile_commit(const TileRegs<T, NV>& t, T* tile, int npix, int cv, int pt, int npt,
-                                               int CB, bool has_pro, const f4& psc, const f4& psh) {
+                                               int CB, bool has_pro, const f22& psc, const f22& psh) {
     if (pt >= npt) return;
     asm volatile("" : "+v"(pt));  // as in dw_tile_fetch: recompute the LDS offsets per tile, do not keep them
     int pix = pt;
@@ -158,12 +151,10 @@ __device__ __forceinline__ void dw_tile_commit(const TileRegs<T, NV>& t, T* tile
         if (pix < npix) {
             T* dst = tile + (unsigned)(pix * CB + cv * 4);
             if (has_pro && ((t.inb >> u) & 1u)) {
-                f4 v = Raw4T<T>::unpack(t.v[u]);
-                v.x = siluf_(v.x * psc.x + psh.x);
-                v.y = siluf_(v.y * psc.y + psh.y);
-                v.z = siluf_(v.z * psc.z + psh.z);
-                v.w = siluf_(v.w * psc.w + psh.w);
-                store4<T>(dst, v);
+                f22 v = Raw4T<T>::unpack22(t.v[u]);
+                v.lo = silu2(v.lo * psc.lo + psh.lo);
+                v.hi = silu2(v.hi * psc.hi + psh.hi);
+                store22<T>(dst, v);
             } else {
                 *reinterpret_cast<typename Raw4T<T>::type*>(dst) = t.v[u];
             }
@@ -206,14 +197,15 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
         const int ts = p.flip ? (K * K - 1 - t) : t;
         wsm[i] = (cc < cbv) ? p.w[(size_t)(c0 + cc) * (K * K) + ts] : 0.f;
     }
-    f4 psc = {1, 1, 1, 1}, psh = {0, 0, 0, 0};
-    if (has_pro && chan_ok) { psc = load4<float>(p.pscale + c); psh = load4<float>(p.pshift + c); }
-    f4 es = {0, 0, 0, 0}, eh = es, em = es, er = es;
+    const f22 zero22 = {v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+    f22 psc = {v2f{1.f, 1.f}, v2f{1.f, 1.f}}, psh = zero22;
+    if (has_pro && chan_ok) { psc = load22<float>(p.pscale + c); psh = load22<float>(p.pshift + c); }
+    f22 es = zero22, eh = zero22, em = zero22, er = zero22;
     if (p.yfwd && cvalid) {
-        es = load4<float>(p.escale + c); eh = load4<float>(p.eshift + c);
-        em = load4<float>(p.emean + c); er = load4<float>(p.erstd + c);
+        es = load22<float>(p.escale + c); eh = load22<float>(p.eshift + c);
+        em = load22<float>(p.emean + c); er = load22<float>(p.erstd + c);
     }
-    f4 st_s = {0, 0, 0, 0}, st_q = {0, 0, 0, 0};
+    f22 st_s = zero22, st_q = zero22;
     __syncthreads();
     const int tiles_per_img = p.tiles_h * p.tiles_w;
     const int total = p.B * tiles_per_img;
@@ -282,7 +274,7 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
                             const int ow = ow0 + owl + q_;
                             if (ow < p.OW) {
                                 const unsigned idx = (unsigned)(((b * p.OH + oh) * p.OW + ow) * p.C + c);
-                                dw_epilogue_store<T>(p, idx, to_f4(acc[a][q_]), es, eh, em, er, st_s, st_q);
+                                dw_epilogue_store<T>(p, idx, acc[a][q_], es, eh, em, er, st_s, st_q);
                             }
                         }
                     }
@@ -318,19 +310,20 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_gather_kernel(DwParams p)
         const int t = i / CB, cc = i - t * CB;
         wsm[i] = (cc < cbv) ? p.w[(size_t)(c0 + cc) * (K * K) + t] : 0.f;
     }
-    f4 es = {0, 0, 0, 0}, eh = es, em = es, er = es;
+    const f22 zero22 = {v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+    f22 es = zero22, eh = zero22, em = zero22, er = zero22;
     if (p.yfwd && cvalid) {
-        es = load4<float>(p.escale + c); eh = load4<float>(p.eshift + c);
-        em = load4<float>(p.emean + c); er = load4<float>(p.erstd + c);
+        es = load22<float>(p.escale + c); eh = load22<float>(p.eshift + c);
+        em = load22<float>(p.emean + c); er = load22<float>(p.erstd + c);
     }
-    f4 st_s = {0, 0, 0, 0}, st_q = {0, 0, 0, 0};
+    f22 st_s = zero22, st_q = zero22;
     __syncthreads();
     const int nrows = p.B * p.H;
     if (cvalid) {
         for (int rowi = blockIdx.x; rowi < nrows; rowi += gridDim.x) {
             const int b = rowi / p.H, ih = rowi - b * p.H;   // wave-uniform: scalar arithmetic
             for (int iw = pt; iw < p.W; iw += npt) {
-                f4 acc = {0.f, 0.f, 0.f, 0.f};
+                f22 acc = zero22;
 #pragma unroll
                 for (int kh = 0; kh < K; ++kh) {
                     const int th = ih + PAD - kh;
@@ -343,8 +336,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_gather_kernel(DwParams p)
                         if (tw < 0 || (tw & 1)) continue;
                         const int ow = tw >> 1;
                         if (ow >= p.OW) continue;
-                        const f4 g = load4<T>(dy + (unsigned)(((b * p.OH + oh) * p.OW + ow) * p.C + c));
-                        fma4(acc, g, load4<float>(wsm + (kh * K + kw) * CB + cv * 4));
+                        const f22 g = load22<T>(dy + (unsigned)(((b * p.OH + oh) * p.OW + ow) * p.C + c));
+                        fma22(acc, g, load22<float>(wsm + (kh * K + kw) * CB + cv * 4));
                     }
                 }
                 const unsigned idx = (unsigned)((rowi * p.W + iw) * p.C + c);
@@ -379,9 +372,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, cons
     const int s_npt = 256 / nvec, s_cv = tid % nvec, s_pt = tid / nvec;
     const bool s_chan_ok = s_cv * 4 < cbv;
     const bool has_pro = p.pscale != nullptr;
-    f4 psc = {1, 1, 1, 1}, psh = {0, 0, 0, 0};
-    if (has_pro && s_chan_ok) { psc = load4<float>(p.pscale + c0 + s_cv * 4); psh = load4<float>(p.pshift + c0 + s_cv * 4); }
-    const f4 one = {1, 1, 1, 1}, zero = {0, 0, 0, 0};
+    const f22 zero = {v2f{0.f, 0.f}, v2f{0.f, 0.f}}, one = {v2f{1.f, 1.f}, v2f{1.f, 1.f}};
+    f22 psc = one, psh = zero;
+    if (has_pro && s_chan_ok) { psc = load22<float>(p.pscale + c0 + s_cv * 4); psh = load22<float>(p.pshift + c0 + s_cv * 4); }
     // compute map: (pixel-thread, tap row, channel vector)
     const int nkc = K * nvec, npt = 256 / nkc;
     const int cv = tid % nvec, kh = (tid / nvec) % K, pt = tid / nkc;

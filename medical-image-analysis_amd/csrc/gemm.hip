@@ -550,7 +550,9 @@ static int launch_nt_(const GemmNTParams& p, int part_rows, hipStream_t stream) 
     q.dump_off = lds;
     lds += 256 * 16;
     const int tiles_m = cdiv(p.M, BM);
-    q.row_slots = p.stats ? part_rows : (tiles_m < 1024 ? tiles_m : 1024);
+    int slot_cap = 1024;
+    if (const char* e = getenv("MIA_NT_SLOTS")) slot_cap = atoi(e);
+    q.row_slots = p.stats ? part_rows : (tiles_m < slot_cap ? tiles_m : slot_cap);
     dim3 grid((unsigned)(cdiv(q.row_slots, 8) * 8 * cdiv(p.N, BN)));
     // wide tiles and prologue variants are short of registers: one stage in flight; narrow plain ones stream: two
     auto kern = gemm_nt_kernel<T, MT, NT, PRO, ((NT <= 6 && !PRO) ? 2 : 1)>;

@@ -33,6 +33,9 @@ __device__ __forceinline__ RowMap make_rowmap(int C, int CB, int block_col, int 
     m.valid = (m.cv * 4 < m.cbv) && (m.pt < m.npt);
     return m;
 }
+__device__ __forceinline__ f22 f22_zero() { return f22{v2f{0.f, 0.f}, v2f{0.f, 0.f}}; }
+__device__ __forceinline__ f22 f22_splat(float a) { return f22{v2f{a, a}, v2f{a, a}}; }
+
 // sum the per-thread f4 pairs over row-threads and write channel sums to outA[c0 + ch] (and outB)
 __device__ __forceinline__ void block_colsum2(float* red, const RowMap& m, int tid, f4 s, f4 q, float* outA,
                                               float* outB) {
@@ -175,45 +178,43 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(T* G, const T* Y
     const RowMap m = make_rowmap(C, CB, blockIdx.y, tid);
     f4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
     if (m.valid) {
-        const f4 sc = load4<float>(scale + m.c), sh = load4<float>(shift + m.c);
-        const f4 mu = load4<float>(mean + m.c), rs = load4<float>(rstd + m.c);
+        const f22 sc = load22<float>(scale + m.c), sh = load22<float>(shift + m.c);
+        const f22 mu = load22<float>(mean + m.c), rs = load22<float>(rstd + m.c);
         const bool writes = (act != MIA_ACT_NONE) || gate || dpool;
         const long long step = (long long)gridDim.x * m.npt;
-        auto body = [&](long long r, f4 g, const f4 y) {
+        f22 s2 = f22_zero(), q2 = f22_zero();
+        auto body = [&](long long r, f22 g, const f22 y) {
             if (gate) {
-                const f4 gt = load4<float>(gate + (size_t)((unsigned)r / (unsigned)rows_per_img) * C + m.c);
-                g.x *= gt.x; g.y *= gt.y; g.z *= gt.z; g.w *= gt.w;
+                const f22 gt = load22<float>(gate + (size_t)((unsigned)r / (unsigned)rows_per_img) * C + m.c);
+                g.lo *= gt.lo; g.hi *= gt.hi;
             }
             if (dpool) {
-                const f4 dp = load4<float>(dpool + (size_t)((unsigned)r / (unsigned)rows_per_img) * C + m.c);
-                g.x += dp.x; g.y += dp.y; g.z += dp.z; g.w += dp.w;
+                const f22 dp = load22<float>(dpool + (size_t)((unsigned)r / (unsigned)rows_per_img) * C + m.c);
+                g.lo += dp.lo; g.hi += dp.hi;
             }
             if (act == MIA_ACT_SILU) {
-                g.x *= silu_gradf_(y.x * sc.x + sh.x);
-                g.y *= silu_gradf_(y.y * sc.y + sh.y);
-                g.z *= silu_gradf_(y.z * sc.z + sh.z);
-                g.w *= silu_gradf_(y.w * sc.w + sh.w);
+                g.lo *= silu_grad2(y.lo * sc.lo + sh.lo);
+                g.hi *= silu_grad2(y.hi * sc.hi + sh.hi);
             }
-            s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
-            q.x += g.x * ((y.x - mu.x) * rs.x);
-            q.y += g.y * ((y.y - mu.y) * rs.y);
-            q.z += g.z * ((y.z - mu.z) * rs.z);
-            q.w += g.w * ((y.w - mu.w) * rs.w);
-            if (writes) store4<T>(G + (size_t)r * C + m.c, g);
+            s2.lo += g.lo; s2.hi += g.hi;
+            q2.lo += g.lo * ((y.lo - mu.lo) * rs.lo);
+            q2.hi += g.hi * ((y.hi - mu.hi) * rs.hi);
+            if (writes) store22<T>(G + (size_t)r * C + m.c, g);
         };
         long long r = (long long)blockIdx.x * m.npt + m.pt;
         // 4 rows per iteration: 8 independent vector loads in flight per lane
         for (; r + 3 * step < R; r += 4 * step) {
-            f4 g[4], y[4];
+            f22 g[4], y[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                g[u] = load4<T>(G + (size_t)(r + u * step) * C + m.c);
-                y[u] = load4<T>(Y + (size_t)(r + u * step) * C + m.c);
+                g[u] = load22<T>(G + (size_t)(r + u * step) * C + m.c);
+                y[u] = load22<T>(Y + (size_t)(r + u * step) * C + m.c);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) body(r + u * step, g[u], y[u]);
         }
-        for (; r < R; r += step) body(r, load4<T>(G + (size_t)r * C + m.c), load4<T>(Y + (size_t)r * C + m.c));
+        for (; r < R; r += step) body(r, load22<T>(G + (size_t)r * C + m.c), load22<T>(Y + (size_t)r * C + m.c));
+        s = to_f4(s2); q = to_f4(q2);
     }
     block_colsum2(red, m, tid, s, q, part + ((size_t)blockIdx.x * 2 + 0) * C, part + ((size_t)blockIdx.x * 2 + 1) * C);
 }
@@ -253,24 +254,24 @@ __global__ __launch_bounds__(256) void affine2_kernel(const T* X, const T* Y, co
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
         const size_t idx = (size_t)i * 4;
         const int c = (int)((unsigned)i % (unsigned)(C >> 2)) << 2;   // 32-bit modulo (host checks the range)
-        f4 x = load4<T>(X + idx);
-        const f4 av = load4<float>(a + c), dv = load4<float>(d + c);
-        f4 o = {x.x * av.x + dv.x, x.y * av.y + dv.y, x.z * av.z + dv.z, x.w * av.w + dv.w};
+        const f22 x = load22<T>(X + idx);
+        const f22 av = load22<float>(a + c), dv = load22<float>(d + c);
+        f22 o = {x.lo * av.lo + dv.lo, x.hi * av.hi + dv.hi};
         if (Y) {
-            const f4 y = load4<T>(Y + idx);
-            const f4 bv = load4<float>(b + c);
-            o.x += y.x * bv.x; o.y += y.y * bv.y; o.z += y.z * bv.z; o.w += y.w * bv.w;
+            const f22 y = load22<T>(Y + idx);
+            const f22 bv = load22<float>(b + c);
+            o.lo += y.lo * bv.lo; o.hi += y.hi * bv.hi;
         }
         if (act == MIA_ACT_SILU) {
-            o.x = siluf_(o.x); o.y = siluf_(o.y); o.z = siluf_(o.z); o.w = siluf_(o.w);
+            o.lo = silu2(o.lo); o.hi = silu2(o.hi);
         } else if (act == MIA_ACT_RELU) {
-            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+            o.lo = __builtin_elementwise_max(o.lo, v2f{0.f, 0.f}); o.hi = __builtin_elementwise_max(o.hi, v2f{0.f, 0.f});
         }
         if (Res) {
-            const f4 r = load4<T>(Res + idx);
-            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            const f22 r = load22<T>(Res + idx);
+            o.lo += r.lo; o.hi += r.hi;
         }
-        store4<T>(Out + idx, o);
+        store22<T>(Out + idx, o);
     }
 }
 
@@ -310,38 +311,32 @@ __global__ __launch_bounds__(256) void img_colsum_kernel(const T* Y, const T* Wt
     const int r_end = (r_begin + rows_per_split) < HW ? (r_begin + rows_per_split) : HW;
     f4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
     if (m.valid) {
-        f4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
-        if (scale) { sc = load4<float>(scale + m.c); sh = load4<float>(shift + m.c); }
+        f22 sc = f22_splat(1.f), sh = f22_zero();
+        if (scale) { sc = load22<float>(scale + m.c); sh = load22<float>(shift + m.c); }
         const T* yb = Y + (size_t)b * HW * C + m.c;
         const T* wb = Wt ? Wt + (size_t)b * HW * C + m.c : nullptr;
+        f22 s2 = f22_zero();
+        auto body = [&](f22 y, const f22 w) {
+            y.lo = y.lo * sc.lo + sh.lo; y.hi = y.hi * sc.hi + sh.hi;
+            if (act == MIA_ACT_SILU) { y.lo = silu2(y.lo); y.hi = silu2(y.hi); }
+            if (wb) { y.lo *= w.lo; y.hi *= w.hi; }
+            s2.lo += y.lo; s2.hi += y.hi;
+        };
         int r = r_begin + m.pt;
         // 4 independent rows per iteration keep several loads in flight per lane
         for (; r + 3 * m.npt < r_end; r += 4 * m.npt) {
-            f4 y[4], w[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) y[u] = load4<T>(yb + (size_t)(r + u * m.npt) * C);
-            if (wb) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) w[u] = load4<T>(wb + (size_t)(r + u * m.npt) * C);
-            }
+            f22 y[4], w[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                f4 v = {y[u].x * sc.x + sh.x, y[u].y * sc.y + sh.y, y[u].z * sc.z + sh.z, y[u].w * sc.w + sh.w};
-                if (act == MIA_ACT_SILU) { v.x = siluf_(v.x); v.y = siluf_(v.y); v.z = siluf_(v.z); v.w = siluf_(v.w); }
-                if (wb) { v.x *= w[u].x; v.y *= w[u].y; v.z *= w[u].z; v.w *= w[u].w; }
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                y[u] = load22<T>(yb + (size_t)(r + u * m.npt) * C);
+                w[u] = wb ? load22<T>(wb + (size_t)(r + u * m.npt) * C) : f22_zero();
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) body(y[u], w[u]);
         }
-        for (; r < r_end; r += m.npt) {
-            f4 y = load4<T>(yb + (size_t)r * C);
-            y.x = y.x * sc.x + sh.x; y.y = y.y * sc.y + sh.y; y.z = y.z * sc.z + sh.z; y.w = y.w * sc.w + sh.w;
-            if (act == MIA_ACT_SILU) { y.x = siluf_(y.x); y.y = siluf_(y.y); y.z = siluf_(y.z); y.w = siluf_(y.w); }
-            if (wb) {
-                const f4 w = load4<T>(wb + (size_t)r * C);
-                y.x *= w.x; y.y *= w.y; y.z *= w.z; y.w *= w.w;
-            }
-            s.x += y.x; s.y += y.y; s.z += y.z; s.w += y.w;
-        }
+        for (; r < r_end; r += m.npt)
+            body(load22<T>(yb + (size_t)r * C), wb ? load22<T>(wb + (size_t)r * C) : f22_zero());
+        s = to_f4(s2);
     }
     block_colsum2(red, m, tid, s, q, out + ((size_t)b * splits + sp) * C, nullptr);
 }
@@ -388,38 +383,41 @@ __global__ __launch_bounds__(256) void se_bwd_sums_kernel(const T* Y, const T* d
     const int rows_per_split = (HW + splits - 1) / splits;
     const int r_begin = sp * rows_per_split;
     const int r_end = (r_begin + rows_per_split) < HW ? (r_begin + rows_per_split) : HW;
-    f4 q0 = {0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0, q4 = q0;
+    f22 a0 = f22_zero(), a1 = a0, a2 = a0, a3 = a0, a4 = a0;
     if (m.valid) {
-        const f4 sc = load4<float>(scale + m.c), sh = load4<float>(shift + m.c);
-        const f4 mu = load4<float>(mean + m.c), rs = load4<float>(rstd + m.c);
+        const f22 sc = load22<float>(scale + m.c), sh = load22<float>(shift + m.c);
+        const f22 mu = load22<float>(mean + m.c), rs = load22<float>(rstd + m.c);
         const T* yb = Y + (size_t)b * HW * C + m.c;
         const T* wb = dZ + (size_t)b * HW * C + m.c;
-#define SE_ACC(E)                                                       \
-    {                                                                   \
-        const float z = y.E * sc.E + sh.E, sg = sigmoidf_(z);           \
-        const float dsl = sg * (1.0f + z * (1.0f - sg));                \
-        const float xh = (y.E - mu.E) * rs.E, dd = dsl * w.E;           \
-        q0.E += w.E * (z * sg);                                         \
-        q1.E += dd;                                                     \
-        q2.E += dd * xh;                                                \
-        q3.E += dsl;                                                    \
-        q4.E += dsl * xh;                                               \
-    }
-        auto body = [&](const f4 y, const f4 w) { SE_ACC(x) SE_ACC(y) SE_ACC(z) SE_ACC(w) };
-#undef SE_ACC
+        auto half = [&](const v2f y, const v2f w, const v2f sc_, const v2f sh_, const v2f mu_, const v2f rs_, v2f& p0,
+                        v2f& p1, v2f& p2, v2f& p3, v2f& p4) {
+            const v2f z = y * sc_ + sh_, sg = sigmoid2(z);
+            const v2f dsl = sg * (1.0f + z * (1.0f - sg));
+            const v2f xh = (y - mu_) * rs_, dd = dsl * w;
+            p0 += w * (z * sg);
+            p1 += dd;
+            p2 += dd * xh;
+            p3 += dsl;
+            p4 += dsl * xh;
+        };
+        auto body = [&](const f22 y, const f22 w) {
+            half(y.lo, w.lo, sc.lo, sh.lo, mu.lo, rs.lo, a0.lo, a1.lo, a2.lo, a3.lo, a4.lo);
+            half(y.hi, w.hi, sc.hi, sh.hi, mu.hi, rs.hi, a0.hi, a1.hi, a2.hi, a3.hi, a4.hi);
+        };
         int r = r_begin + m.pt;
         for (; r + 3 * m.npt < r_end; r += 4 * m.npt) {
-            f4 y[4], w[4];
+            f22 y[4], w[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                y[u] = load4<T>(yb + (size_t)(r + u * m.npt) * C);
-                w[u] = load4<T>(wb + (size_t)(r + u * m.npt) * C);
+                y[u] = load22<T>(yb + (size_t)(r + u * m.npt) * C);
+                w[u] = load22<T>(wb + (size_t)(r + u * m.npt) * C);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) body(y[u], w[u]);
         }
-        for (; r < r_end; r += m.npt) body(load4<T>(yb + (size_t)r * C), load4<T>(wb + (size_t)r * C));
+        for (; r < r_end; r += m.npt) body(load22<T>(yb + (size_t)r * C), load22<T>(wb + (size_t)r * C));
     }
+    const f4 q0 = to_f4(a0), q1 = to_f4(a1), q2 = to_f4(a2), q3 = to_f4(a3), q4 = to_f4(a4);
     const size_t plane = (size_t)B * splits * C, row = ((size_t)b * splits + sp) * C;
     block_colsum2(red, m, tid, q0, q1, out + row, out + plane + row);
     block_colsum2(red, m, tid, q2, q3, out + 2 * plane + row, out + 3 * plane + row);
@@ -484,24 +482,21 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(T* G, const T* Y,
     for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < nvec; i += gridDim.x * 256) {
         const size_t idx = (size_t)i * 4;
         const int c = (int)(i % cvec) << 2;
-        f4 g = load4<T>(G + idx);
-        const f4 y = load4<T>(Y + idx);
+        f22 g = load22<T>(G + idx);
+        const f22 y = load22<T>(Y + idx);
         if (gate) {
             const size_t go = (size_t)(i / vec_per_img) * C + c;
-            const f4 gt = load4<float>(gate + go), dp = load4<float>(dpool + go);
-            g.x = g.x * gt.x + dp.x; g.y = g.y * gt.y + dp.y; g.z = g.z * gt.z + dp.z; g.w = g.w * gt.w + dp.w;
+            const f22 gt = load22<float>(gate + go), dp = load22<float>(dpool + go);
+            g.lo = g.lo * gt.lo + dp.lo; g.hi = g.hi * gt.hi + dp.hi;
         }
         if (act == MIA_ACT_SILU) {
-            const f4 sc = load4<float>(scale + c), sh = load4<float>(shift + c);
-            g.x *= silu_gradf_(y.x * sc.x + sh.x);
-            g.y *= silu_gradf_(y.y * sc.y + sh.y);
-            g.z *= silu_gradf_(y.z * sc.z + sh.z);
-            g.w *= silu_gradf_(y.w * sc.w + sh.w);
+            const f22 sc = load22<float>(scale + c), sh = load22<float>(shift + c);
+            g.lo *= silu_grad2(y.lo * sc.lo + sh.lo);
+            g.hi *= silu_grad2(y.hi * sc.hi + sh.hi);
         }
-        const f4 a = load4<float>(ca + c), bb = load4<float>(cb + c), d = load4<float>(cd + c);
-        const f4 o = {a.x * g.x + bb.x * y.x + d.x, a.y * g.y + bb.y * y.y + d.y, a.z * g.z + bb.z * y.z + d.z,
-                      a.w * g.w + bb.w * y.w + d.w};
-        store4<T>(G + idx, o);
+        const f22 a = load22<float>(ca + c), bb = load22<float>(cb + c), d = load22<float>(cd + c);
+        const f22 o = {a.lo * g.lo + bb.lo * y.lo + d.lo, a.hi * g.hi + bb.hi * y.hi + d.hi};
+        store22<T>(G + idx, o);
     }
 }
 

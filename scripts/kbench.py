@@ -67,6 +67,7 @@ CASES["gemm_proj6"] = lambda: gemm_case(B * 100, 384, 2304, True, True)
 CASES["gemm_proj11_noact"] = lambda: gemm_case(B * 75 * 75, 32, 192, True, True, act=ops.ACT_NONE)
 CASES["gemm_proj11_nogate"] = lambda: gemm_case(B * 75 * 75, 32, 192, True, True, use_gate=False)
 CASES["gemm_proj11_plain"] = lambda: gemm_case(B * 75 * 75, 32, 192, False, True)
+CASES["gemm_dz10"] = lambda: gemm_case(B * 150 * 150, 144, 24, False, False)
 CASES["gemm_dz11"] = lambda: gemm_case(B * 75 * 75, 192, 32, False, False)
 
 def tn_case(M, N, K, pro):
@@ -109,6 +110,20 @@ for mode in ("fwd", "bwd"):
     CASES[f"se{mode}_s4"] = (lambda m=mode: se_case(816, 34, 361, m))
     CASES[f"se{mode}_s3"] = (lambda m=mode: se_case(576, 24, 361, m))
     CASES[f"se{mode}_s2"] = (lambda m=mode: se_case(288, 12, 1444, m))
+
+def _fill_case():
+    x = torch.empty(512 * 1024 * 1024, dtype=torch.bfloat16, device="cuda")
+    return (lambda: x.zero_()), x.numel() * 2
+def _copy_case():
+    x = torch.empty(256 * 1024 * 1024, dtype=torch.bfloat16, device="cuda")
+    y = torch.empty_like(x)
+    return (lambda: y.copy_(x)), x.numel() * 4
+def _read_case():
+    x = torch.ones(512 * 1024 * 1024, dtype=torch.bfloat16, device="cuda")
+    return (lambda: x.sum()), x.numel() * 2
+CASES["raw_fill"] = _fill_case
+CASES["raw_copy"] = _copy_case
+CASES["raw_read"] = _read_case
 
 def main():
     names = sys.argv[1].split(",") if len(sys.argv) > 1 else list(CASES)
