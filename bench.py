@@ -24,7 +24,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (spec)
 FAMILIES = ["gemm_nt", "gemm_tn", "dwconv_fwd", "dwconv_bwd_data", "dwconv_bwd_weight", "bn_act_bwd_reduce",
-            "affine2", "img_colsum"]
+            "affine2", "img_colsum", "se_bwd_sums", "bn_act_bwd_apply"]
+# HBM bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, scripts/pmc_traffic.sh), by kernel
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 TRAIN_GFLOP_PER_IMG = {"b3_cbam": 11.00, "b3_plain": 10.60}   # 3 x forward FLOPs at 300x300
 
 
@@ -87,6 +89,7 @@ def main():
     from mia_amd import ops
     from mia_amd import preprocess as PP
     from mia_amd.ddp import GradReducer
+    from mia_amd.head_ops import CrossEntropyLoss
     from mia_amd.src.model import FoundationModel
     mia_amd.lib().mia_check_device()
 
@@ -104,10 +107,12 @@ def main():
     x = PP.resize_normalize(raw, (300, 300))
     y = torch.from_numpy(np.random.default_rng(99 + rank).integers(0, 4, args.batch)).to(dev)
 
+    criterion = CrossEntropyLoss()
+
     def step():
         reducer.zero_grad()
         logits = model(x, "classification", "synthetic")
-        loss = torch.nn.functional.cross_entropy(logits.float(), y)
+        loss = criterion(logits, y)
         loss.backward()
         reducer.finish()
         opt.step()
@@ -145,6 +150,14 @@ def main():
         ips = world * args.batch * args.steps / dt
         launches, ms, nbytes = rec
         achieved = (nbytes / (ms * 1e-3)) / 1e9 if ms > 0 else 0.0
+        traffic = None
+        try:
+            with open(TRAFFIC_FILE) as f:
+                fam = json.load(f)["families"].get(dominant)
+            if fam and args.batch == 128 and args.dtype == "bf16" and args.workload == "b3_cbam":
+                traffic = int(fam["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "train images/sec (whole node) EffNet-B3+CBAM 300x300 bf16",
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -157,7 +170,7 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "model_tflops_per_s": round(ips * TRAIN_GFLOP_PER_IMG[args.workload] / 1e3, 1)},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launches_per_step": launches / max(args.steps, 1),
                          "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2),
                          "algorithmic_bytes_per_launch": int(nbytes / max(launches, 1))},
