@@ -9,7 +9,7 @@
 // incremental: no integer division.
 //
 //   dwconv_fwd        y = dw(pro(x))                      + per-channel sum/sumsq partials (BN stats)
-//   data-gradient     stride 1: the same kernel with flipped taps; stride 2: row-gather kernel
+//   data-gradient     stride 1: the same kernel with flipped taps; stride 2: parity-unrolled tile kernel
 //                     both with the fused epilogue g = dA * silu'(z), partials sum(g), sum(g*xhat)
 //   dwconv_bwd_weight dW[c][kh][kw] = sum dY * pro(x)     (per-workgroup partial slab + ordered reduce)
 #include "common.h"
@@ -288,16 +288,22 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
     if (p.stats) dw_write_stats(p, red, tid, nvec, npt, c0, cbv, st_s, st_q);
 }
 
-// stride-2 data gradient by gathering, one image row per workgroup iteration:
-//   dA[ih,iw,c] = sum_{kh,kw} dY[(ih+PAD-kh)/2, (iw+PAD-kw)/2, c] * w[c,kh,kw]  over the taps with even offsets
+// Stride-2 data gradient on LDS tiles. A "cell" is one dY position (r, c); it owns the 2x2 block of dA pixels
+// (2r+pr, 2c+pc). For an output of parity pr only the taps kh = (pr+PAD) mod 2 (+2, +4) contribute, from dY row
+// r + (pr+PAD-kh)/2, i.e. r-1, r or r+1 -- all static once the parity is fixed, so the tap loops unroll with no
+// parity tests, no bounds tests (the halo is staged as zeros) and each dY vector is read from LDS once per patch.
+// A thread computes 1 x 2 cells = 2 x 4 output pixels for one 4-channel vector.
+//   p.x = dY [B,OH,OW,C], p.y = dA [B,H,W,C], p.yfwd = forward tensor at the dA positions (fused silu' epilogue)
 template <typename T, int K>
-__global__ __launch_bounds__(256) void dwconv_bwd_data_gather_kernel(DwParams p) {
-    // here: p.x = dY [B,OH,OW,C]; p.y = dA [B,H,W,C]; p.yfwd = forward raw input-side tensor [B,H,W,C]
+__global__ __launch_bounds__(256) void dwconv_bwd_data_s2_kernel(DwParams p) {
     constexpr int PAD = (K - 1) / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int CB = p.CB;
-    float* wsm = reinterpret_cast<float*>(smem);  // [K*K][CB]
-    float* red = wsm + K * K * CB;                // [256][8]
+    const int CB = p.CB, TH = p.TH, TW = p.TW;       // tile in cells
+    const int IHT = TH + 2, IWT = TW + 2;            // staged dY window: one cell of halo on every side
+    float* wsm = reinterpret_cast<float*>(smem);     // [K*K][CB]
+    float* red = wsm + K * K * CB;                   // [256][8]
+    T* tile = reinterpret_cast<T*>(red + 256 * 8);   // [IHT][IWT][CB]
+
     const T* __restrict__ dy = reinterpret_cast<const T*>(p.x);
     const int tid = threadIdx.x;
     const int c0 = blockIdx.y * CB;
@@ -305,7 +311,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_gather_kernel(DwParams p)
     const int nvec = CB / 4, npt = 256 / nvec;
     const int cv = tid % nvec, pt = tid / nvec;
     const int c = c0 + cv * 4;
-    const bool cvalid = (cv * 4 < cbv) && (pt < npt);
+    const bool chan_ok = cv * 4 < cbv;
+    const bool cvalid = chan_ok && (pt < npt);
     for (int i = tid; i < K * K * CB; i += 256) {
         const int t = i / CB, cc = i - t * CB;
         wsm[i] = (cc < cbv) ? p.w[(size_t)(c0 + cc) * (K * K) + t] : 0.f;
@@ -318,30 +325,80 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_gather_kernel(DwParams p)
     }
     f22 st_s = zero22, st_q = zero22;
     __syncthreads();
-    const int nrows = p.B * p.H;
-    if (cvalid) {
-        for (int rowi = blockIdx.x; rowi < nrows; rowi += gridDim.x) {
-            const int b = rowi / p.H, ih = rowi - b * p.H;   // wave-uniform: scalar arithmetic
-            for (int iw = pt; iw < p.W; iw += npt) {
-                f22 acc = zero22;
+    const int tiles_per_img = p.tiles_h * p.tiles_w;
+    const int total = p.B * tiles_per_img;
+    const int patches_w = TW / 2;
+    const int npatch = TH * patches_w;
+    const int dph = npt / patches_w, dpw = npt - dph * patches_w;
+
+    TileRegs<T, DW_NV> regs;
+    auto fetch = [&](int work) {
+        const int b = work / tiles_per_img;
+        const int tr = work - b * tiles_per_img;
+        const int trh = tr / p.tiles_w;
+        const int r0 = trh * TH, q0 = (tr - trh * p.tiles_w) * TW;
+        dw_tile_fetch<T, DW_NV>(regs, dy + (size_t)b * p.OH * p.OW * p.C, IHT, IWT, r0 - 1, q0 - 1, p.OH, p.OW, p.C, c,
+                                chan_ok, pt, npt);
+    };
+    if ((int)blockIdx.x < total) fetch(blockIdx.x);
+    for (int work = blockIdx.x; work < total; work += gridDim.x) {
+        const int b = work / tiles_per_img;
+        const int tr = work - b * tiles_per_img;
+        const int trh = tr / p.tiles_w;
+        const int r0 = trh * TH, q0 = (tr - trh * p.tiles_w) * TW;
+        __syncthreads();
+        dw_tile_commit<T, DW_NV>(regs, tile, IHT * IWT, cv, pt, npt, CB, false, zero22, zero22);
+        __syncthreads();
+        if (work + (int)gridDim.x < total) fetch(work + gridDim.x);
+        if (cvalid) {
+            int ptc = pt;
+            asm volatile("" : "+v"(ptc));
+            int ph = ptc / patches_w, pw = ptc - ph * patches_w;
+            for (int patch = ptc; patch < npatch; patch += npt) {
+                const int rl = ph, ql = pw * 2;   // first cell of the patch, tile-local
+                // dY window of the patch: rows rl-1..rl+1, cols ql-1..ql+2 (tile-local + 1 for the halo)
+                f22 in[3][4];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        in[a][j] = load22<T>(tile + (unsigned)(((rl + a) * IWT + ql + j) * CB + cv * 4));
+                f22 acc[2][4];
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                    for (int x_ = 0; x_ < 4; ++x_) acc[pr][x_] = zero22;
 #pragma unroll
                 for (int kh = 0; kh < K; ++kh) {
-                    const int th = ih + PAD - kh;
-                    if (th < 0 || (th & 1)) continue;
-                    const int oh = th >> 1;
-                    if (oh >= p.OH) continue;
+                    const int pr = (kh + PAD) & 1;             // output row parity this tap row serves
+                    const int dh = (pr + PAD - kh) / 2;        // exact: the numerator is even; in {-1, 0, 1}
 #pragma unroll
                     for (int kw = 0; kw < K; ++kw) {
-                        const int tw = iw + PAD - kw;
-                        if (tw < 0 || (tw & 1)) continue;
-                        const int ow = tw >> 1;
-                        if (ow >= p.OW) continue;
-                        const f22 g = load22<T>(dy + (unsigned)(((b * p.OH + oh) * p.OW + ow) * p.C + c));
-                        fma22(acc, g, load22<float>(wsm + (kh * K + kw) * CB + cv * 4));
+                        const int pc = (kw + PAD) & 1;
+                        const int dw = (pc + PAD - kw) / 2;
+                        const f22 wv = load22<float>(wsm + (unsigned)((kh * K + kw) * CB + cv * 4));
+#pragma unroll
+                        for (int cell = 0; cell < 2; ++cell)
+                            fma22(acc[pr][cell * 2 + pc], in[dh + 1][cell + dw + 1], wv);
                     }
                 }
-                const unsigned idx = (unsigned)((rowi * p.W + iw) * p.C + c);
-                dw_epilogue_store<T>(p, idx, acc, es, eh, em, er, st_s, st_q);
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int ih = (r0 + rl) * 2 + pr;
+                    if (ih < p.H) {
+#pragma unroll
+                        for (int x_ = 0; x_ < 4; ++x_) {
+                            const int iw = (q0 + ql) * 2 + x_;
+                            if (iw < p.W) {
+                                const unsigned idx = (unsigned)(((b * p.H + ih) * p.W + iw) * p.C + c);
+                                dw_epilogue_store<T>(p, idx, acc[pr][x_], es, eh, em, er, st_s, st_q);
+                            }
+                        }
+                    }
+                }
+                ph += dph;
+                pw += dpw;
+                if (pw >= patches_w) { pw -= patches_w; ++ph; }
             }
         }
     }
@@ -611,16 +668,26 @@ extern "C" int mia_dwconv_bwd_data(int dtype, const void* dy, int B, int H, int 
         MIA_CHECK_ARG(rc == 0, "mia_dwconv_bwd_data: no kernel for K=%d", K);
     } else {
         p.x = dy; p.y = dx; p.H = H; p.W = W; p.OH = OH; p.OW = OW;
-        const long long nrows = (long long)B * H;
-        const int gx = stats ? part_rows : (int)(nrows < 8192 ? nrows : 8192);
-        const size_t lds = (size_t)K * K * p.CB * 4 + 256 * 8 * 4;
+        // tiles are counted in dY cells (each cell = 2x2 dA pixels); the staged window has one cell of halo a side
+        pick_tile(OH, OW, 3, 1, p.CB, elem, 1, DW_NV, 0, dtype == MIA_BF16 ? 32768 : 65536, &p.TH, &p.TW);
+        p.tiles_h = cdiv(OH, p.TH); p.tiles_w = cdiv(OW, p.TW);
+        const int total = B * p.tiles_h * p.tiles_w;
+        int gx = total < 8192 ? total : 8192;
+        if (stats) {
+            if (gx > part_rows) gx = part_rows;
+            if (gx < part_rows) {
+                hipError_t e = hipMemsetAsync(stats + (size_t)gx * 2 * C, 0, (size_t)(part_rows - gx) * 2 * C * sizeof(float), s);
+                MIA_CHECK_ARG(e == hipSuccess, "mia_dwconv_bwd_data: memset failed: %s", hipGetErrorString(e));
+            }
+        }
+        const size_t lds = (size_t)K * K * p.CB * 4 + 256 * 8 * 4 + (size_t)(p.TH + 2) * (p.TW + 2) * p.CB * elem;
         dim3 grid(gx, cdiv(C, p.CB));
         if (dtype == MIA_BF16) {
-            if (K == 3) hipLaunchKernelGGL((dwconv_bwd_data_gather_kernel<bf16_t, 3>), grid, dim3(256), lds, s, p);
-            else hipLaunchKernelGGL((dwconv_bwd_data_gather_kernel<bf16_t, 5>), grid, dim3(256), lds, s, p);
+            if (K == 3) hipLaunchKernelGGL((dwconv_bwd_data_s2_kernel<bf16_t, 3>), grid, dim3(256), lds, s, p);
+            else hipLaunchKernelGGL((dwconv_bwd_data_s2_kernel<bf16_t, 5>), grid, dim3(256), lds, s, p);
         } else {
-            if (K == 3) hipLaunchKernelGGL((dwconv_bwd_data_gather_kernel<float, 3>), grid, dim3(256), lds, s, p);
-            else hipLaunchKernelGGL((dwconv_bwd_data_gather_kernel<float, 5>), grid, dim3(256), lds, s, p);
+            if (K == 3) hipLaunchKernelGGL((dwconv_bwd_data_s2_kernel<float, 3>), grid, dim3(256), lds, s, p);
+            else hipLaunchKernelGGL((dwconv_bwd_data_s2_kernel<float, 5>), grid, dim3(256), lds, s, p);
         }
     }
     MIA_CHECK_LAUNCH("mia_dwconv_bwd_data");
