@@ -165,6 +165,28 @@ __device__ __forceinline__ void dw_tile_commit(const TileRegs<T, NV>& t, T* tile
     }
 }
 
+// Which tiles a workgroup walks. Consecutive block ids land on different XCDs (each with its own L2), so the tile
+// list is cut into eight contiguous ranges, one per XCD, and the XCD's workgroups stride through their range
+// together: tiles that share halo rows are then in flight on the same L2. Falls back to a plain grid stride when
+// the grid is not a multiple of eight.
+struct TileWalk {
+    int base, count, first, stride;
+};
+__device__ __forceinline__ TileWalk make_tile_walk(int total) {
+    TileWalk w;
+    if (gridDim.x & 7) {
+        w.base = 0; w.count = total; w.first = blockIdx.x; w.stride = gridDim.x;
+    } else {
+        const int per = (total + 7) >> 3, xcd = blockIdx.x & 7;
+        w.base = xcd * per;
+        w.count = total - w.base < per ? total - w.base : per;
+        if (w.count < 0) w.count = 0;
+        w.first = blockIdx.x >> 3;
+        w.stride = gridDim.x >> 3;
+    }
+    return w;
+}
+
 constexpr int DW_NV = 16;   // pixels per thread in a staged input tile (forward / data-gradient kernel)
 constexpr int DW_NVX = 12;  // weight-gradient kernel: input tile
 constexpr int DW_NVD = 8;   //                          output-gradient tile
@@ -222,8 +244,10 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
         dw_tile_fetch<T, DW_NV>(regs, x + (size_t)b * p.H * p.W * p.C, IHT, IWT, oh0 * S - PAD, ow0 * S - PAD, p.H, p.W,
                                 p.C, c, chan_ok, pt, npt);
     };
-    if ((int)blockIdx.x < total) fetch(blockIdx.x);
-    for (int work = blockIdx.x; work < total; work += gridDim.x) {
+    const TileWalk walk = make_tile_walk(total);
+    if (walk.first < walk.count) fetch(walk.base + walk.first);
+    for (int wi = walk.first; wi < walk.count; wi += walk.stride) {
+        const int work = walk.base + wi;
         const int b = work / tiles_per_img;
         const int tr = work - b * tiles_per_img;
         const int trh = tr / p.tiles_w;
@@ -231,7 +255,7 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
         __syncthreads();  // previous tile fully consumed
         dw_tile_commit<T, DW_NV>(regs, tile, IHT * IWT, cv, pt, npt, CB, has_pro, psc, psh);
         __syncthreads();
-        if (work + (int)gridDim.x < total) fetch(work + gridDim.x);  // in flight while this tile is computed
+        if (wi + walk.stride < walk.count) fetch(work + walk.stride);  // in flight while this tile is computed
         if (cvalid) {
             int ptc = pt;
             asm volatile("" : "+v"(ptc));  // patch walk recomputed per tile, not hoisted (registers)
@@ -340,8 +364,10 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_s2_kernel(DwParams p) {
         dw_tile_fetch<T, DW_NV>(regs, dy + (size_t)b * p.OH * p.OW * p.C, IHT, IWT, r0 - 1, q0 - 1, p.OH, p.OW, p.C, c,
                                 chan_ok, pt, npt);
     };
-    if ((int)blockIdx.x < total) fetch(blockIdx.x);
-    for (int work = blockIdx.x; work < total; work += gridDim.x) {
+    const TileWalk walk = make_tile_walk(total);
+    if (walk.first < walk.count) fetch(walk.base + walk.first);
+    for (int wi = walk.first; wi < walk.count; wi += walk.stride) {
+        const int work = walk.base + wi;
         const int b = work / tiles_per_img;
         const int tr = work - b * tiles_per_img;
         const int trh = tr / p.tiles_w;
@@ -349,7 +375,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_s2_kernel(DwParams p) {
         __syncthreads();
         dw_tile_commit<T, DW_NV>(regs, tile, IHT * IWT, cv, pt, npt, CB, false, zero22, zero22);
         __syncthreads();
-        if (work + (int)gridDim.x < total) fetch(work + gridDim.x);
+        if (wi + walk.stride < walk.count) fetch(work + walk.stride);
         if (cvalid) {
             int ptc = pt;
             asm volatile("" : "+v"(ptc));
@@ -459,13 +485,15 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, cons
         dw_tile_fetch<T, DW_NVD>(dregs, dy + (size_t)b * p.OH * p.OW * p.C, TH, TW, oh0, ow0, p.OH, p.OW, p.C,
                                  c0 + s_cv * 4, s_chan_ok, s_pt, s_npt);
     };
-    if ((int)blockIdx.x < total) fetch(blockIdx.x);
-    for (int work = blockIdx.x; work < total; work += gridDim.x) {
+    const TileWalk walk = make_tile_walk(total);
+    if (walk.first < walk.count) fetch(walk.base + walk.first);
+    for (int wi = walk.first; wi < walk.count; wi += walk.stride) {
+        const int work = walk.base + wi;
         __syncthreads();
         dw_tile_commit<T, DW_NVX>(xregs, tile, IHT * IWT, s_cv, s_pt, s_npt, CB, has_pro, psc, psh);
         dw_tile_commit<T, DW_NVD>(dregs, dtile, TH * TW, s_cv, s_pt, s_npt, CB, false, one, zero);
         __syncthreads();
-        if (work + (int)gridDim.x < total) fetch(work + gridDim.x);  // in flight while this tile is reduced
+        if (wi + walk.stride < walk.count) fetch(work + walk.stride);  // in flight while this tile is reduced
         if (cvalid) {
             int ph = pt / patches_w, pw = pt - ph * patches_w;
             for (int patch = pt; patch < npatch; patch += npt) {
