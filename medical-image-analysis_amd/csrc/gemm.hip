@@ -570,11 +570,11 @@ template <typename T>
 static int dispatch_nt(const GemmNTParams& p, int part_rows, hipStream_t stream) {
     static const int widths[] = {32, 48, 96, 128, 144, 192, 240};
     int best = 128;
-    long long best_cost = -1;
+    double best_cost = -1.0;
     for (int w : widths) {
-        const long long padded = (long long)cdiv(p.N, w) * w;
-        // wasted columns first, then fewer column tiles (A is streamed once per column tile)
-        const long long cost = padded * 64 + cdiv(p.N, w);
+        // columns computed (padding included), with a per-tile overhead that favours wide tiles: every column tile
+        // re-streams the A rows and re-runs the prologue, and narrow tiles feed the MFMAs poorly
+        const double cost = (double)cdiv(p.N, w) * w * (1.0 + 32.0 / w);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = w; }
     }
     if (const char* e = getenv("MIA_GEMM_BN")) best = atoi(e);

@@ -332,16 +332,17 @@ class MBConvFn(torch.autograd.Function):
         dt = x.dtype
         k, s = cfg.k, cfg.s
         training = cfg.bn_dw.training
+        need_bwd = any(ctx.needs_input_grad)   # inference: skip the transposed weight copies
         # ---- expansion (ir only) ----
         if cfg.kind == "ir":
             M = B * H * W
-            wexp, _ = cast_weight(_w2d(w_exp), dt)
+            wexp, wexpT = cast_weight(_w2d(w_exp), dt, want_t=need_bwd)   # [Cm, Cin] and, for the backward, [Cin, Cm]
             y1, part = gemm_nt(x.view(M, Cin), wexp, stats_rows=part_rows((M + 63) // 64) if training else 0)
             st1 = bn_finalize_fwd(part, M, cfg.bn_exp)
             y1 = y1.view(B, H, W, -1)
             dw_in, dw_sc, dw_sh = y1, st1[0], st1[1]
         else:
-            y1, st1 = None, None
+            y1, st1, wexpT = None, None, None
             dw_in, dw_sc, dw_sh = x, None, None
         Cm = dw_in.shape[-1]
         # ---- depthwise ----
@@ -358,7 +359,7 @@ class MBConvFn(torch.autograd.Function):
         _, weT = cast_weight(_w2d(w_see), torch.float32, want=False, want_t=True)  # [RD, Cm]
         pooled, hpre, gate = se_gate_fwd(pool_part, OH * OW, wr, b_ser.detach(), weT, b_see.detach())
         # ---- projection ----
-        wproj, _ = cast_weight(_w2d(w_proj), dt)
+        wproj, wprojT = cast_weight(_w2d(w_proj), dt, want_t=need_bwd)   # [Co, Cm] and [Cm, Co]
         y3, part = gemm_nt(y2.view(M2, Cm), wproj, pscale=st2[0], pshift=st2[1], pro_act=ACT_SILU, gate=gate,
                            rows_per_img=OH * OW, stats_rows=part_rows((M2 + 63) // 64) if training else 0)
         st3 = bn_finalize_fwd(part, M2, cfg.bn_proj)
@@ -366,6 +367,8 @@ class MBConvFn(torch.autograd.Function):
         y3 = y3.view(B, OH, OW, Co)
         out = affine2(y3, st3[0], st3[1], res=x if cfg.has_skip else None)
         ctx.cfg, ctx.training = cfg, training
+        # casts made once per step: the transposed copies serve the data-gradient GEMMs of the backward
+        ctx.wexpT, ctx.wprojT, ctx.weT = wexpT, wprojT, weT
         ctx.save_for_backward(x, y1, st1, y2, st2, y3, st3, pooled, hpre, gate, w_exp, g1, w_dw, g2, w_ser, w_see,
                               w_proj, g3)
         return out
@@ -389,13 +392,11 @@ class MBConvFn(torch.autograd.Function):
         # ---- projection: weight and data gradients ----
         dwproj = gemm_tn(dy3, y2.view(M2, Cm), pscale=st2[0], pshift=st2[1], pro_act=ACT_SILU, gate=gate,
                          rows_per_img=OH * OW)
-        _, wprojT = cast_weight(_w2d(w_proj), dt, want=False, want_t=True)  # [Cm, Co]
-        dz, _ = gemm_nt(dy3, wprojT)
+        dz, _ = gemm_nt(dy3, ctx.wprojT)
         dz = dz.view(B, OH, OW, Cm)
         # ---- squeeze-excite backward ----
         sums = se_bwd_sums(y2, dz, st2)
-        wr = _w2d(w_ser)
-        _, weT = cast_weight(_w2d(w_see), torch.float32, want=False, want_t=True)  # [RD, Cm]
+        wr, weT = _w2d(w_ser), ctx.weT
         dpool, dwr, dbr, dwe, dbe = se_gate_bwd(sums[0], OH * OW, wr, weT, gate, hpre, pooled)
         # ---- bn after depthwise (+SiLU): its reductions come from the same per-image sums ----
         c2 = bn_finalize_bwd(se_bn_combine(sums, gate, dpool), M2, g2, st2, training)
@@ -410,8 +411,7 @@ class MBConvFn(torch.autograd.Function):
             c1 = bn_finalize_bwd(part, M, g1, st1, training)
             dy1 = affine2(g1t, c1[2], c1[4], y=y1, b=c1[3], out=g1t).view(M, Cm)
             dwexp = gemm_tn(dy1, x.view(M, Cin))
-            _, wexpT = cast_weight(_w2d(w_exp), dt, want=False, want_t=True)  # [Cin, Cm]
-            dx, _ = gemm_nt(dy1, wexpT, add=dout.view(M, Cin) if cfg.has_skip else None)
+            dx, _ = gemm_nt(dy1, ctx.wexpT, add=dout.view(M, Cin) if cfg.has_skip else None)
             dx = dx.view(B, H, W, Cin)
             return (dx, dwexp.view_as(w_exp), c1[0], c1[1], ddw, c2[0], c2[1], dwr.view_as(w_ser), dbr,
                     dwe.view_as(w_see), dbe, dwproj.view_as(w_proj), c3[0], c3[1], None)
