@@ -176,3 +176,34 @@ def test_errors_and_api_contract():
         assert tuple(mine(x, "classification", "alz").shape) == (1, 4)
     f = mine.backbone(x)
     assert [t.shape[1] for t in f] == [24, 32, 48, 136, 384]
+
+
+def test_c5_finetune_path_fp32_inference():
+    """Finetune/inference path (finetune.py:99-113, inference.py:102-110): trunk weights from a checkpoint that
+    still carries timm's classifier/conv_head/bn2 keys, loaded through load_model_weights_safely; a new 4-class
+    head added afterwards; eval-mode fp32 inference at 224x224. Logits within 1e-4 of the oracle, same top-1."""
+    ref = O.OracleFoundationModel({"pretrain": 3}, dropout=0.2, use_attention=True)
+    sd = seeded_state_dict(ref, 21)
+    ref.load_state_dict(sd)
+    ckpt = {k: v for k, v in sd.items() if k.startswith("backbone.")}
+    ckpt["backbone.classifier.weight"] = torch.zeros(1000, 1536)
+    ckpt["backbone.conv_head.weight"] = torch.zeros(1536, 384, 1, 1)
+    ckpt["backbone.bn2.running_mean"] = torch.zeros(1536)
+    mine = create_foundation_model(backbone="efficientnet_b3", pretrained=False, classification_heads={})
+    missing, unexpected = load_model_weights_safely(mine, {"model_state_dict": ckpt}, suppress_warnings=True)
+    assert not missing
+    assert sorted(unexpected) == ["backbone.bn2.running_mean", "backbone.classifier.weight", "backbone.conv_head.weight"]
+    mine.cuda()
+    mine.add_classification_head("alzheimer", 4)
+    head_sd = seeded_state_dict(mine.classification_layers["alzheimer"], 22)
+    mine.classification_layers["alzheimer"].load_state_dict(head_sd)
+    ref.classification_layers["alzheimer"] = O.MultiHeadAttentionClassifier(384, 8, 4, 0.2)
+    ref.classification_layers["alzheimer"].load_state_dict(head_sd)
+    x = randn(23, 16, 3, 224, 224)
+    ref.eval()
+    mine.eval()
+    with torch.no_grad():
+        lr = ref(x, "classification", "alzheimer")
+        lm = mine(x.cuda(), "classification", "alzheimer")
+    assert relerr(lm, lr) < 1e-4
+    assert bool((lm.argmax(1).cpu() == lr.argmax(1)).all())
