@@ -90,6 +90,7 @@ def main():
     from mia_amd import preprocess as PP
     from mia_amd.ddp import GradReducer
     from mia_amd.head_ops import CrossEntropyLoss
+    from mia_amd.optim import AdamW
     from mia_amd.src.model import FoundationModel
     mia_amd.lib().mia_check_device()
 
@@ -100,7 +101,7 @@ def main():
                             compute_dtype=args.dtype).to(dev).train()
     reducer = GradReducer(model.parameters())
     reducer.broadcast_parameters(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+    opt = AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
 
     # synthetic MRI-shaped batch, preprocessed on the device by the resize+normalise kernel, resident in HBM
     raw = torch.from_numpy(phantom_batch(args.batch, 1234 + rank)).to(dev)

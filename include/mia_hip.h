@@ -184,6 +184,15 @@ int mia_zero_slice_filter(const void* vol, int elem_bytes, int is_float, long lo
 int mia_gather_slices(const void* vol, int elem_bytes, long long n_slices, long long slice_elems, const int* idx,
                       const int* count, void* out, void* stream);
 
+/* ---- optimizer: torch.optim.AdamW as configured at train.py:193-197 / finetune.py:232-248 --------------------------
+ * One multi-tensor pass over (param, grad, exp_avg, exp_avg_sq), all fp32 and contiguous. params/grads/exp_avg/
+ * exp_avg_sq are HOST arrays of n_tensors DEVICE pointers, sizes a host array of element counts; step is the 1-based
+ * number of this update; gradients are multiplied by grad_scale first. Arithmetic = torch's AdamW step:
+ * p *= 1-lr*wd; m = lerp(m,g,1-b1); v = b2*v+(1-b2)*g*g; p -= lr/(1-b1^t) * m/(sqrt(v)/sqrt(1-b2^t)+eps). */
+int mia_adamw_step(int n_tensors, const void* const* params, const void* const* grads, const void* const* exp_avg,
+                   const void* const* exp_avg_sq, const long long* sizes, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, int step, double grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

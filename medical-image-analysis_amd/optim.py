@@ -1,0 +1,62 @@
+"""AdamW on the device through the multi-tensor HIP kernel (mia_adamw_step).
+
+Same constructor arguments, param_groups and state-dict layout (step / exp_avg / exp_avg_sq) as torch.optim.AdamW,
+which the reference builds at train.py:193-197 and finetune.py:232-248, so LR schedulers
+(ReduceLROnPlateau, train.py:199-201) and optimizer checkpoints (train.py:440) keep working."""
+import ctypes
+
+import torch
+
+from ._lib import lib
+from .ops import _stream
+
+
+class AdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError("invalid AdamW hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._tables = {}
+
+    def _table(self, gi, ps):
+        """ctypes pointer tables of one group, rebuilt only when the set of (param, grad) storages changes."""
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
+        cached = self._tables.get(gi)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        n = len(ps)
+        arr = ctypes.c_void_p * n
+        st = [self.state[p] for p in ps]
+        tab = (n, arr(*[p.data_ptr() for p in ps]), arr(*[p.grad.data_ptr() for p in ps]),
+               arr(*[s["exp_avg"].data_ptr() for s in st]), arr(*[s["exp_avg_sq"].data_ptr() for s in st]),
+               (ctypes.c_longlong * n)(*[p.numel() for p in ps]))
+        self._tables[gi] = (key, tab)
+        return tab
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            for p in ps:
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or p.grad.is_sparse:
+                    raise RuntimeError("mia_amd.optim.AdamW needs contiguous fp32 parameters on an MI355X device")
+                if not p.grad.is_contiguous():
+                    p.grad = p.grad.contiguous()
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+            step = int(self.state[ps[0]]["step"].item())
+            n, tp, tg, tm, tv, sizes = self._table(gi, ps)
+            b1, b2 = group["betas"]
+            lib().mia_adamw_step(n, tp, tg, tm, tv, sizes, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                 float(group["weight_decay"]), step, float(grad_scale), _stream())
+        return loss
