@@ -13,7 +13,7 @@ from ._lib import lib
 F32, BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
-MAX_PART = 1024
+MAX_PART = 512   # persistent workgroups (= BatchNorm partial rows) per launch: two per CU measured best
 
 
 def _p(t: Optional[torch.Tensor]):
