@@ -165,6 +165,32 @@ template <>
 __device__ __forceinline__ void store22<bf16_t>(bf16_t* p, const f22& v) {
     *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.lo), pack_bf16x2(v.hi));
 }
+// eight consecutive channels as two f22: ONE 16-byte access per lane for bf16 (the width at which HBM streams best),
+// two for fp32
+template <typename T>
+__device__ __forceinline__ void load44(const T* p, f22& a, f22& b);
+template <>
+__device__ __forceinline__ void load44<float>(const float* p, f22& a, f22& b) {
+    a = load22<float>(p);
+    b = load22<float>(p + 4);
+}
+template <>
+__device__ __forceinline__ void load44<bf16_t>(const bf16_t* p, f22& a, f22& b) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    a = {unpack_bf16x2(v.x), unpack_bf16x2(v.y)};
+    b = {unpack_bf16x2(v.z), unpack_bf16x2(v.w)};
+}
+template <typename T>
+__device__ __forceinline__ void store44(T* p, const f22& a, const f22& b);
+template <>
+__device__ __forceinline__ void store44<float>(float* p, const f22& a, const f22& b) {
+    store22<float>(p, a);
+    store22<float>(p + 4, b);
+}
+template <>
+__device__ __forceinline__ void store44<bf16_t>(bf16_t* p, const f22& a, const f22& b) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(a.lo), pack_bf16x2(a.hi), pack_bf16x2(b.lo), pack_bf16x2(b.hi));
+}
 __device__ __forceinline__ f4 to_f4(const f22& v) { return {v.lo.x, v.lo.y, v.hi.x, v.hi.y}; }
 __device__ __forceinline__ f22 to_f22(const f4& v) { return {v2f{v.x, v.y}, v2f{v.z, v.w}}; }
 

@@ -275,6 +275,43 @@ __global__ __launch_bounds__(256) void affine2_kernel(const T* X, const T* Y, co
     }
 }
 
+// the same, eight channels per thread (C % 8 == 0): one 16-byte access per lane and operand for bf16
+template <typename T>
+__global__ __launch_bounds__(256) void affine2_wide_kernel(const T* X, const T* Y, const T* Res, T* Out, unsigned nvec8,
+                                                           int C, const float* a, const float* b, const float* d,
+                                                           int act) {
+    const unsigned cvec = (unsigned)C >> 3;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < nvec8; i += gridDim.x * 256) {
+        const size_t idx = (size_t)i * 8;
+        const int c = (int)(i % cvec) << 3;
+        f22 x0, x1;
+        load44<T>(X + idx, x0, x1);
+        const f22 a0 = load22<float>(a + c), a1 = load22<float>(a + c + 4);
+        const f22 d0 = load22<float>(d + c), d1 = load22<float>(d + c + 4);
+        f22 o0 = {x0.lo * a0.lo + d0.lo, x0.hi * a0.hi + d0.hi}, o1 = {x1.lo * a1.lo + d1.lo, x1.hi * a1.hi + d1.hi};
+        if (Y) {
+            f22 y0, y1;
+            load44<T>(Y + idx, y0, y1);
+            const f22 b0 = load22<float>(b + c), b1 = load22<float>(b + c + 4);
+            o0.lo += y0.lo * b0.lo; o0.hi += y0.hi * b0.hi;
+            o1.lo += y1.lo * b1.lo; o1.hi += y1.hi * b1.hi;
+        }
+        if (act == MIA_ACT_SILU) {
+            o0.lo = silu2(o0.lo); o0.hi = silu2(o0.hi); o1.lo = silu2(o1.lo); o1.hi = silu2(o1.hi);
+        } else if (act == MIA_ACT_RELU) {
+            const v2f z = {0.f, 0.f};
+            o0.lo = __builtin_elementwise_max(o0.lo, z); o0.hi = __builtin_elementwise_max(o0.hi, z);
+            o1.lo = __builtin_elementwise_max(o1.lo, z); o1.hi = __builtin_elementwise_max(o1.hi, z);
+        }
+        if (Res) {
+            f22 r0, r1;
+            load44<T>(Res + idx, r0, r1);
+            o0.lo += r0.lo; o0.hi += r0.hi; o1.lo += r1.lo; o1.hi += r1.hi;
+        }
+        store44<T>(Out + idx, o0, o1);
+    }
+}
+
 extern "C" int mia_affine2(int dtype, const void* X, const void* Y, const void* Res, void* Out, long long R, int C,
                            const float* a, const float* b, const float* d, int act, void* stream) {
     MIA_CHECK_ARG(X && Out && a && d && R > 0 && C > 0 && C % 4 == 0, "mia_affine2: bad arguments");
@@ -284,6 +321,20 @@ extern "C" int mia_affine2(int dtype, const void* X, const void* Y, const void* 
     long long blocks = (nvec + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool aligned16 = (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)Res | (uintptr_t)Out) & 15) == 0;
+    if (C % 8 == 0 && aligned16) {
+        const long long nvec8 = nvec / 2;
+        long long wblocks = (nvec8 + 255) / 256;
+        if (wblocks > 16384) wblocks = 16384;
+        if (dtype == MIA_BF16)
+            hipLaunchKernelGGL(affine2_wide_kernel<bf16_t>, dim3((unsigned)wblocks), dim3(256), 0, s, (const bf16_t*)X,
+                               (const bf16_t*)Y, (const bf16_t*)Res, (bf16_t*)Out, (unsigned)nvec8, C, a, b, d, act);
+        else
+            hipLaunchKernelGGL(affine2_wide_kernel<float>, dim3((unsigned)wblocks), dim3(256), 0, s, (const float*)X,
+                               (const float*)Y, (const float*)Res, (float*)Out, (unsigned)nvec8, C, a, b, d, act);
+        MIA_CHECK_LAUNCH("mia_affine2");
+        return 0;
+    }
     if (dtype == MIA_BF16)
         hipLaunchKernelGGL(affine2_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)X,
                            (const bf16_t*)Y, (const bf16_t*)Res, (bf16_t*)Out, nvec, C, a, b, d, act);
@@ -472,20 +523,16 @@ extern "C" int mia_se_bn_combine(const float* sums, int B, int splits, int C, co
 }
 
 // dy = ca * [act'(z) * (G*gate[b] + dpool[b])] + cb*y + cd, written over G   (z = scale*y + shift)
-template <typename T>
+// W = channels per thread: 4, or 8 (one 16-byte access per lane for bf16) when C % 8 == 0
+template <typename T, int W>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(T* G, const T* Y, unsigned nvec, int C,
                                                                const float* scale, const float* shift, int act,
                                                                const float* gate, const float* dpool,
                                                                unsigned vec_per_img, const float* ca, const float* cb,
                                                                const float* cd) {
-    const unsigned cvec = (unsigned)C >> 2;
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < nvec; i += gridDim.x * 256) {
-        const size_t idx = (size_t)i * 4;
-        const int c = (int)(i % cvec) << 2;
-        f22 g = load22<T>(G + idx);
-        const f22 y = load22<T>(Y + idx);
+    const unsigned cvec = (unsigned)C / W;
+    auto four = [&](f22& g, const f22& y, int c, size_t go) {
         if (gate) {
-            const size_t go = (size_t)(i / vec_per_img) * C + c;
             const f22 gt = load22<float>(gate + go), dp = load22<float>(dpool + go);
             g.lo = g.lo * gt.lo + dp.lo; g.hi = g.hi * gt.hi + dp.hi;
         }
@@ -495,8 +542,25 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(T* G, const T* Y,
             g.hi *= silu_grad2(y.hi * sc.hi + sh.hi);
         }
         const f22 a = load22<float>(ca + c), bb = load22<float>(cb + c), d = load22<float>(cd + c);
-        const f22 o = {a.lo * g.lo + bb.lo * y.lo + d.lo, a.hi * g.hi + bb.hi * y.hi + d.hi};
-        store22<T>(G + idx, o);
+        g = f22{a.lo * g.lo + bb.lo * y.lo + d.lo, a.hi * g.hi + bb.hi * y.hi + d.hi};
+    };
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < nvec; i += gridDim.x * 256) {
+        const size_t idx = (size_t)i * W;
+        const int c = (int)(i % cvec) * W;
+        const size_t go = (size_t)(i / vec_per_img) * C + c;
+        if constexpr (W == 8) {
+            f22 g0, g1, y0, y1;
+            load44<T>(G + idx, g0, g1);
+            load44<T>(Y + idx, y0, y1);
+            four(g0, y0, c, go);
+            four(g1, y1, c + 4, go + 4);
+            store44<T>(G + idx, g0, g1);
+        } else {
+            f22 g = load22<T>(G + idx);
+            const f22 y = load22<T>(Y + idx);
+            four(g, y, c, go);
+            store22<T>(G + idx, g);
+        }
     }
 }
 
@@ -508,18 +572,20 @@ extern "C" int mia_bn_act_bwd_apply(int dtype, void* G, const void* Y, long long
     MIA_CHECK_ARG(act == MIA_ACT_NONE || (scale && shift), "mia_bn_act_bwd_apply: activation needs scale/shift");
     MIA_CHECK_ARG(!(gate == nullptr) == !(dpool == nullptr), "mia_bn_act_bwd_apply: gate/dpool must come together");
     MIA_CHECK_ARG(!gate || rows_per_img > 0, "mia_bn_act_bwd_apply: gate needs rows_per_img");
-    const long long nvec = R * C / 4;
+    const bool wide = (C % 8 == 0) && ((((uintptr_t)G | (uintptr_t)Y) & 15) == 0);
+    const int W = wide ? 8 : 4;
+    const long long nvec = R * C / W;
     MIA_CHECK_ARG(nvec < (1LL << 32), "mia_bn_act_bwd_apply: tensor too large");
     long long blocks = (nvec + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    const unsigned vpi = (unsigned)((long long)(rows_per_img > 0 ? rows_per_img : 1) * C / 4);
+    const unsigned vpi = (unsigned)((long long)(rows_per_img > 0 ? rows_per_img : 1) * C / W);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (bf16_t*)G,
-                           (const bf16_t*)Y, (unsigned)nvec, C, scale, shift, act, gate, dpool, vpi, ca, cb, cd);
-    else
-        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (float*)G,
-                           (const float*)Y, (unsigned)nvec, C, scale, shift, act, gate, dpool, vpi, ca, cb, cd);
+#define MIA_APPLY(T_, W_)                                                                                          \
+    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T_, W_>), dim3((unsigned)blocks), dim3(256), 0, s, (T_*)G, (const T_*)Y, \
+                       (unsigned)nvec, C, scale, shift, act, gate, dpool, vpi, ca, cb, cd)
+    if (dtype == MIA_BF16) { if (wide) MIA_APPLY(bf16_t, 8); else MIA_APPLY(bf16_t, 4); }
+    else { if (wide) MIA_APPLY(float, 8); else MIA_APPLY(float, 4); }
+#undef MIA_APPLY
     MIA_CHECK_LAUNCH("mia_bn_act_bwd_apply");
     return 0;
 }
