@@ -13,7 +13,6 @@
 //                     both with the fused epilogue g = dA * silu'(z), partials sum(g), sum(g*xhat)
 //   dwconv_bwd_weight dW[c][kh][kw] = sum dY * pro(x)     (per-workgroup partial slab + ordered reduce)
 #include "common.h"
-#include <stdlib.h>
 
 #define DW_PW 4  // output pixels per patch row
 
@@ -33,10 +32,6 @@ struct DwParams {
     float* stats;  // [gridDim.x][2][C] (nullable)
     int CB, TH, TW, tiles_h, tiles_w;
 };
-
-__device__ __forceinline__ void fma4(f4& acc, const f4& a, const f4& b) {
-    acc.x += a.x * b.x; acc.y += a.y * b.y; acc.z += a.z * b.z; acc.w += a.w * b.w;
-}
 
 // Four channels as two explicit 2-vectors (f22): each 2-vector op is one packed-f32 instruction on a naturally
 // paired register couple. (Left to itself the vectoriser pairs values across taps and spends a move per packed FMA.)
@@ -577,7 +572,6 @@ static int pick_cb(int C) {
 // per thread, within an LDS budget.
 static void pick_tile(int OH, int OW, int K, int S, int CB, int elem, int ph, int max_in, int max_out, int lds_budget,
                       int* th, int* tw) {
-    if (const char* e = getenv("MIA_DW_LDS")) lds_budget = atoi(e);  // tuning knob
     static const int ths[] = {2, 4, 6, 8, 10, 12, 16, 20};
     static const int tws[] = {4, 8, 12, 16, 20, 24, 32, 40};
     const int npt = 256 / (CB / 4);

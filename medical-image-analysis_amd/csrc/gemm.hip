@@ -10,7 +10,6 @@
 //
 // Storage type T is float (exact-f32 MFMA 16x16x4) or bf16 (MFMA 16x16x32); accumulation is fp32.
 #include "common.h"
-#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
@@ -96,35 +95,6 @@ struct Vec16<bf16_t> {
 
 // a 16-byte chunk held in registers between the global load and the LDS store
 typedef uint4 raw16;
-template <typename T>
-__device__ __forceinline__ void raw_unpack(const raw16& r, float* o);
-template <>
-__device__ __forceinline__ void raw_unpack<float>(const raw16& r, float* o) {
-    o[0] = __uint_as_float(r.x); o[1] = __uint_as_float(r.y); o[2] = __uint_as_float(r.z); o[3] = __uint_as_float(r.w);
-}
-template <>
-__device__ __forceinline__ void raw_unpack<bf16_t>(const raw16& r, float* o) {
-    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        o[2 * i] = __uint_as_float(w[i] << 16);
-        o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
-    }
-}
-template <typename T>
-__device__ __forceinline__ raw16 raw_pack(const float* o);
-template <>
-__device__ __forceinline__ raw16 raw_pack<float>(const float* o) {
-    return make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
-}
-template <>
-__device__ __forceinline__ raw16 raw_pack<bf16_t>(const float* o) {
-    uint32_t w[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(v2f{o[2 * i], o[2 * i + 1]});
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
 // BatchNorm + SiLU (+ gate) on one 16-byte chunk, two channels per instruction.
 // sc/sh/g point at VEC consecutive floats (registers after inlining); g may be null.
 template <typename T>
@@ -543,16 +513,13 @@ static int launch_nt_(const GemmNTParams& p, int part_rows, hipStream_t stream) 
     const int red_bytes = 4 * BN * 2 * (int)sizeof(float);
     // private strips cost LDS: keep them separate only while three workgroups still fit a CU
     q.alias_cs = (stage_bytes + strip_bytes) * 3 > 160 * 1024 ? 1 : 0;
-    if (const char* e = getenv("MIA_GEMM_ALIAS")) q.alias_cs = atoi(e);
     int lds = q.alias_cs ? (stage_bytes > strip_bytes ? stage_bytes : strip_bytes) : stage_bytes + strip_bytes;
     if (lds < red_bytes) lds = red_bytes;
     lds = (lds + 15) & ~15;
     q.dump_off = lds;
     lds += 256 * 16;
     const int tiles_m = cdiv(p.M, BM);
-    int slot_cap = 1024;
-    if (const char* e = getenv("MIA_NT_SLOTS")) slot_cap = atoi(e);
-    q.row_slots = p.stats ? part_rows : (tiles_m < slot_cap ? tiles_m : slot_cap);
+    q.row_slots = p.stats ? part_rows : (tiles_m < 1024 ? tiles_m : 1024);
     dim3 grid((unsigned)(cdiv(q.row_slots, 8) * 8 * cdiv(p.N, BN)));
     // wide tiles and prologue variants are short of registers: one stage in flight; narrow plain ones stream: two
     auto kern = gemm_nt_kernel<T, MT, NT, PRO, ((NT <= 6 && !PRO) ? 2 : 1)>;
@@ -577,7 +544,6 @@ static int dispatch_nt(const GemmNTParams& p, int part_rows, hipStream_t stream)
         const double cost = (double)cdiv(p.N, w) * w * (1.0 + 32.0 / w);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = w; }
     }
-    if (const char* e = getenv("MIA_GEMM_BN")) best = atoi(e);
     // few row tiles: halve the tile height so that the grid still covers the chip
     const bool small_m = (long long)cdiv(p.M, 128) * cdiv(p.N, best) < 384 && p.M > 64;
     switch (best) {
@@ -834,9 +800,7 @@ extern "C" int mia_gemm_tn(int dtype, const void* G, int ldg, const void* X, int
     const int tiles = cdiv(N, 128) * cdiv(K, 128);
     const long long chunks = ((long long)M + BR - 1) / BR;
     // aim for ~512 blocks (two per CU; more splits cost more atomic traffic), at least 4 reduction chunks each
-    long long target_blocks = 512;
-    if (const char* e = getenv("MIA_TN_BLOCKS")) target_blocks = atoi(e);
-    long long splits = target_blocks / tiles;
+    long long splits = 512 / tiles;
     if (splits < 1) splits = 1;
     if (splits > (chunks + 3) / 4) splits = (chunks + 3) / 4;
     if (splits < 1) splits = 1;
