@@ -62,6 +62,74 @@ def run_module(mod, x, train: bool, full_grads: bool):
     return res
 
 
+def import_reference_loss():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    from src import loss as ref_loss  # type: ignore
+    sys.path.pop(0)
+    return ref_loss
+
+
+def seg_feature_sizes(size):
+    """Spatial sizes of the five trunk features for a size x size input (3x3/5x5 stride-2 convs with 'same' pad)."""
+    out, s = [], size
+    for _ in range(5):
+        s = (s - 1) // 2 + 1
+        out.append(s)
+    return out
+
+
+def run_decoder(dec, feats, size, train, full):
+    dec.train(train)
+    feats = [f.clone().requires_grad_(True) for f in feats]
+    out = dec(feats, (size, size))
+    res = {"out": out.detach().numpy()}
+    if train:
+        out.backward(randn(778, *out.shape))
+        for i, f in enumerate(feats):
+            res[f"dfeat{i}"] = f.grad.numpy() if full else grad_digest(f.grad)
+        for k, p in dec.named_parameters():
+            res["grad." + k] = p.grad.numpy() if full else grad_digest(p.grad)
+        for k, b in dec.named_buffers():
+            if "running" in k:
+                res["buf." + k] = b.detach().numpy().copy()
+    return res
+
+
+def segmentation_goldens(ref):
+    """G9: DecoderBlock, UNetDecoder, EnhancedUNetDecoder (model.py:179-237, :417-494) with dropout 0 so train mode is
+    deterministic; G10: the segmentation losses (loss.py:27-80, :105-136)."""
+    chans = [24, 32, 48, 136, 384]
+    for train in (True, False):
+        m = load_seeded(ref.DecoderBlock(24, 16, dropout=0.0), 51)
+        r = run_module(m, randn(52, 2, 24, 6, 7), train, True)
+        np.savez_compressed(os.path.join(HERE, f"decblock_24_16_6x7_{'train' if train else 'eval'}.npz"), **r)
+    for (cls, tag) in ((ref.EnhancedUNetDecoder, "enhanced"), (ref.UNetDecoder, "unet")):
+        for (size, ncls) in ((64, 3), (45, 1)):
+            sizes = seg_feature_sizes(size)
+            for train in (True, False):
+                dec = load_seeded(cls(chans, num_classes=ncls, dropout=0.0), 61)
+                feats = [randn(62 + i, 2, c, s, s) for i, (c, s) in enumerate(zip(chans, sizes))]
+                r = run_decoder(dec, feats, size, train, False)
+                np.savez_compressed(os.path.join(HERE, f"dec_{tag}_{size}_n{ncls}_{'train' if train else 'eval'}.npz"), **r)
+    ref_loss = import_reference_loss()
+    rng = np.random.default_rng(71)
+    for (n, h, w, tag) in ((3, 17, 19, "n3"), (1, 8, 8, "n1"), (4, 32, 32, "n4")):
+        logits = randn(72 + n, 2, n, h, w, scale=2.0)
+        target = torch.from_numpy(rng.integers(0, n, (2, h, w)).astype(np.int64))
+        weights = torch.from_numpy((0.5 + rng.random(n)).astype(np.float32))
+        res = {"logits": logits.numpy(), "target": target.numpy(), "weights": weights.numpy()}
+        for (name, crit) in (("combined", ref_loss.CombinedSegmentationLoss(num_classes=n)),
+                             ("combined_w", ref_loss.CombinedSegmentationLoss(num_classes=n, weights=weights)),
+                             ("dice", ref_loss.DiceLoss(num_classes=n)), ("iou", ref_loss.IoULoss(num_classes=n))):
+            lg = logits.clone().requires_grad_(True)
+            loss = crit(lg, target)
+            loss.backward()
+            res[name + ".loss"] = np.float64(loss.item())
+            res[name + ".dlogits"] = lg.grad.numpy()
+        np.savez_compressed(os.path.join(HERE, f"segloss_{tag}.npz"), **res)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(1)
@@ -125,6 +193,7 @@ def main():
         for k, v in counts.items():
             f.write(f"{k}={v}\n")
     print(counts)
+    segmentation_goldens(ref)
     print("state-dict keys of MHA head:", list(ref.MultiHeadAttentionClassifier(384, 8, 4).state_dict().keys()))
 
 
