@@ -65,10 +65,13 @@ int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int W, int C, 
  *      (src/model.py:16) ------------------------------------------------------------------------------------
  * training: batch statistics from part (count = rows reduced), running stats updated in place (unbiased
  * variance), *num_batches_tracked += 1. eval: statistics = running stats. Outputs: scale = gamma*rstd,
- * shift = beta - mean*scale, mean, rstd. */
+ * shift = beta - mean*scale, mean, rstd. conv_bias (nullable): the normalised tensor is y + conv_bias[c] (a biased
+ * convolution, DecoderBlock src/model.py:477-480) while only the bias-free y is stored: the outputs are relative to
+ * y, the running mean tracks y + bias. */
 int mia_bn_finalize_fwd(const float* part, int P, int C, double count, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
-                        float eps, int training, float* scale, float* shift, float* mean, float* rstd, void* stream);
+                        float eps, int training, const float* conv_bias, float* scale, float* shift, float* mean,
+                        float* rstd, void* stream);
 /* part holds partials of (sum g, sum g*xhat). Outputs dgamma, dbeta (nullable) and the coefficients of
  * dy = ca*g + cb*y + cd (y = raw pre-BN tensor). */
 int mia_bn_finalize_bwd(const float* part, int P, int C, double count, const float* gamma, const float* mean,
@@ -192,6 +195,42 @@ int mia_gather_slices(const void* vol, int elem_bytes, long long n_slices, long 
 int mia_adamw_step(int n_tensors, const void* const* params, const void* const* grads, const void* const* exp_avg,
                    const void* const* exp_avg_sq, const long long* sizes, double lr, double beta1, double beta2,
                    double eps, double weight_decay, int step, double grad_scale, void* stream);
+
+/* ---- segmentation decoders (src/model.py:179-237 EnhancedUNetDecoder, :417-468 UNetDecoder, :471-494
+ *      DecoderBlock) and losses (src/loss.py:27-80 CombinedSegmentationLoss/DiceLoss, :105-136 IoULoss) ----------
+ * 3x3 / stride 1 / pad 1 convolution (nn.Conv2d(cin, cout, 3, padding=1), model.py:477,479) = im2col + mia_gemm_nt
+ * with the weight as [cout][tap][cin]: col[pix][tap][c] = gate[b][c] * act(scale[c]*x + shift[c]) of the shifted
+ * pixel, zero outside the image (scale/shift, gate optional: BatchNorm apply, ReLU and the Dropout2d mask of the
+ * producing layer). C % 4 == 0. */
+int mia_im2col3x3(int dtype, const void* x, int B, int H, int W, int C, const float* scale, const float* shift, int act,
+                  const float* gate, void* col, void* stream);
+/* data gradient of the lowering: dx[b,h,w,c] = sum_taps dcol[(b,h-dy,w-dx)][tap][c]. */
+int mia_col2im3x3(int dtype, const void* dcol, int B, int H, int W, int C, void* dx, void* stream);
+/* F.interpolate(x, size=(H,W), mode='bilinear', align_corners=False) followed by torch.cat([x, skip], dim=1)
+ * (model.py:227-228, :235 with C2 = 0 / skip = NULL): out [B,H,W,C1+C2] from x [B,h,w,C1] and skip [B,H,W,C2]. */
+int mia_upsample_concat_fwd(int dtype, const void* x, int B, int h, int w, int C1, const void* skip, int C2, int H,
+                            int W, void* out, void* stream);
+/* its gradient: dx [B,h,w,C1] gathered from dout [B,H,W,C1+C2], dskip [B,H,W,C2] = the trailing channels. */
+int mia_upsample_concat_bwd(int dtype, const void* dout, int B, int h, int w, int C1, int C2, int H, int W, void* dx,
+                            void* dskip, void* stream);
+/* final_conv = nn.Conv2d(16, num_classes, 1) (model.py:214, :237): logits [B][n][HW] fp32 (NCHW) from x [B,HW,C];
+ * Wt [n][C], bias [n] (nullable). C % 4 == 0, C <= 64, n <= 8. */
+int mia_pixel_linear_fwd(int dtype, const void* x, int B, int HW, int C, int n, const float* Wt, const float* bias,
+                         float* logits, void* stream);
+/* dx [B,HW,C]; partial [partial_rows][n*C + n] = per-workgroup sums of (dWt, dbias): column-sum them. */
+int mia_pixel_linear_bwd(int dtype, const void* x, const float* dlogits, int B, int HW, int C, int n, const float* Wt,
+                         void* dx, float* partial, int partial_rows, void* stream);
+/* nn.Dropout2d mask (model.py:481): mask[b][c] = 0 with probability p, else 1/(1-p); counter-based, from seed. */
+int mia_channel_dropout_mask(float* mask, int B, int C, float p, unsigned long long seed, void* stream);
+/* loss = ce_weight * CrossEntropy(logits, target, weight=class_weights) + overlap_weight * (1 - mean score),
+ * score = Dice (iou = 0) or IoU (iou = 1) per (image, class) on softmax probabilities. logits [B][n][HW] fp32,
+ * target [B][HW] int64, n <= 8. partial: [B*splits][3n+2] scratch; coef: [1 + 2*B*n] kept for the backward. */
+int mia_seg_loss_fwd(const float* logits, const long long* target, int B, int HW, int n, const float* class_weights,
+                     int iou, float smooth, float ce_weight, float overlap_weight, int splits, float* partial,
+                     float* coef, float* loss, void* stream);
+/* dlogits = upstream[0] * d loss / d logits (upstream: device scalar, NULL = 1). */
+int mia_seg_loss_bwd(const float* logits, const long long* target, int B, int HW, int n, const float* class_weights,
+                     const float* coef, const float* upstream, float* dlogits, void* stream);
 
 #ifdef __cplusplus
 }

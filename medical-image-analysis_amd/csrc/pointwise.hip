@@ -61,11 +61,14 @@ __device__ __forceinline__ void block_colsum2(float* red, const RowMap& m, int t
 __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* part, int P, int C, double count,
                                                               const float* gamma, const float* beta, float* rmean,
                                                               float* rvar, long long* nbt, float momentum, float eps,
-                                                              int training, float* scale, float* shift, float* mean,
-                                                              float* rstd) {
+                                                              int training, const float* conv_bias,
+                                                              float* scale, float* shift, float* mean, float* rstd) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 4 + wave;
     if (c >= C) return;
+    // conv_bias: the normalised tensor is (y + conv_bias[c]) but only the bias-free y is stored; the returned
+    // mean/shift are relative to y, the running mean tracks y + bias
+    const float cb = conv_bias ? conv_bias[c] : 0.f;
     float mu, var;
     if (training) {
         double s = 0.0, q = 0.0;
@@ -85,12 +88,12 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* part,
         var = (float)v;
         if (lane == 0 && rmean) {
             const double unb = count > 1.0 ? v * count / (count - 1.0) : v;
-            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (mu + cb);
             rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
             if (c == 0 && nbt) *nbt += 1;
         }
     } else {
-        mu = rmean[c];
+        mu = rmean[c] - cb;
         var = rvar[c];
     }
     if (lane == 0) {
@@ -106,13 +109,14 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* part,
 extern "C" int mia_bn_finalize_fwd(const float* part, int P, int C, double count, const float* gamma,
                                    const float* beta, float* running_mean, float* running_var,
                                    long long* num_batches_tracked, float momentum, float eps, int training,
-                                   float* scale, float* shift, float* mean, float* rstd, void* stream) {
+                                   const float* conv_bias, float* scale, float* shift, float* mean, float* rstd,
+                                   void* stream) {
     MIA_CHECK_ARG(C > 0 && scale && shift && mean && rstd, "mia_bn_finalize_fwd: bad arguments");
     MIA_CHECK_ARG(!training || (part && P > 0 && count > 0), "mia_bn_finalize_fwd: training needs partials");
     MIA_CHECK_ARG(training || (running_mean && running_var), "mia_bn_finalize_fwd: eval needs running stats");
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        part, P, C, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
-                       training, scale, shift, mean, rstd);
+                       training, conv_bias, scale, shift, mean, rstd);
     MIA_CHECK_LAUNCH("mia_bn_finalize_fwd");
     return 0;
 }
@@ -195,6 +199,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(T* G, const T* Y
             if (act == MIA_ACT_SILU) {
                 g.lo *= silu_grad2(y.lo * sc.lo + sh.lo);
                 g.hi *= silu_grad2(y.hi * sc.hi + sh.hi);
+            } else if (act == MIA_ACT_RELU) {
+                const v2f zl = y.lo * sc.lo + sh.lo, zh = y.hi * sc.hi + sh.hi;
+                g.lo = v2f{zl.x > 0.f ? g.lo.x : 0.f, zl.y > 0.f ? g.lo.y : 0.f};
+                g.hi = v2f{zh.x > 0.f ? g.hi.x : 0.f, zh.y > 0.f ? g.hi.y : 0.f};
             }
             s2.lo += g.lo; s2.hi += g.hi;
             q2.lo += g.lo * ((y.lo - mu.lo) * rs.lo);

@@ -145,14 +145,15 @@ class BNState:
         self.training = bn.training or bn.running_mean is None
 
 
-def bn_finalize_fwd(part, count, bn: BNState):
+def bn_finalize_fwd(part, count, bn: BNState, conv_bias=None):
     C = bn.weight.shape[0]
     dev = bn.weight.device
     out = torch.empty((4, C), dtype=torch.float32, device=dev)
     P = part.shape[0] if part is not None else 0
     lib().mia_bn_finalize_fwd(_p(part), P, C, float(count), _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
                               _p(bn.running_var), _p(bn.nbt), float(bn.momentum), float(bn.eps),
-                              1 if bn.training else 0, _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _stream())
+                              1 if bn.training else 0, _p(conv_bias), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]),
+                              _stream())
     return out  # rows: scale, shift, mean, rstd
 
 

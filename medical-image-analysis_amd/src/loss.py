@@ -1,0 +1,92 @@
+"""Drop-in for the reference's `src.loss` import surface (/root/reference/foundation_model/src/loss.py): the same
+class names, constructor arguments and `get_loss_function` dispatch, computed by the gfx950 loss kernels."""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from mia_amd import seg_ops  # `mia_amd` is registered by src/__init__.py
+from mia_amd.head_ops import CrossEntropyLoss as _DeviceCrossEntropy
+
+
+class DiceLoss(nn.Module):
+    """loss.py:49-80: 1 - mean over (image, class) of (2I + s) / (P + T + s) on softmax probabilities."""
+
+    def __init__(self, num_classes: int = 2, smooth: float = 1e-5):
+        super().__init__()
+        self.num_classes, self.smooth = num_classes, smooth
+
+    def forward(self, predictions, targets):
+        _check_classes(predictions, self.num_classes)
+        return seg_ops.seg_loss(predictions, targets, iou=False, smooth=self.smooth, ce_weight=0.0, overlap_weight=1.0)
+
+
+class IoULoss(nn.Module):
+    """loss.py:105-136: 1 - mean over (image, class) of (I + s) / (P + T - I + s)."""
+
+    def __init__(self, num_classes: int = 2, smooth: float = 1e-5):
+        super().__init__()
+        self.num_classes, self.smooth = num_classes, smooth
+
+    def forward(self, predictions, targets):
+        _check_classes(predictions, self.num_classes)
+        return seg_ops.seg_loss(predictions, targets, iou=True, smooth=self.smooth, ce_weight=0.0, overlap_weight=1.0)
+
+
+class CombinedSegmentationLoss(nn.Module):
+    """loss.py:27-46: ce_weight * CrossEntropy(weight=weights) + dice_weight * Dice, one fused pass."""
+
+    def __init__(self, num_classes: int = 2, weights: Optional[torch.Tensor] = None, dice_weight: float = 0.5,
+                 ce_weight: float = 0.5):
+        super().__init__()
+        self.num_classes, self.dice_weight, self.ce_weight = num_classes, dice_weight, ce_weight
+        self.weights = weights
+        self.smooth = 1e-5
+
+    def forward(self, predictions, targets):
+        _check_classes(predictions, self.num_classes)
+        w = self.weights.to(predictions.device) if self.weights is not None else None
+        return seg_ops.seg_loss(predictions, targets, class_weights=w, iou=False, smooth=self.smooth,
+                                ce_weight=self.ce_weight, overlap_weight=self.dice_weight)
+
+
+class CombinedLoss(nn.Module):
+    """loss.py:8-24."""
+
+    def __init__(self, task: str, num_classes: int = None, weights: Optional[torch.Tensor] = None):
+        super().__init__()
+        self.task, self.num_classes = task, num_classes
+        if task == "classification":
+            if weights is not None:
+                raise NotImplementedError("class-weighted classification cross-entropy is not built")
+            self.criterion = _DeviceCrossEntropy()
+        elif task == "segmentation":
+            self.criterion = CombinedSegmentationLoss(num_classes=num_classes, weights=weights)
+        else:
+            raise ValueError(f"Unknown task: {task}")
+
+    def forward(self, predictions, targets):
+        return self.criterion(predictions, targets)
+
+
+def _check_classes(predictions, num_classes):
+    if predictions.dim() != 4 or predictions.shape[1] != num_classes:
+        raise ValueError(f"expected logits [B, {num_classes}, H, W], got {tuple(predictions.shape)}")
+
+
+def get_loss_function(task: str, num_classes: int = None, loss_type: str = "default",
+                      class_weights: Optional[torch.Tensor] = None):
+    """loss.py:139-160. The focal variants are not built (the default configuration never selects them)."""
+    if loss_type == "focal":
+        raise NotImplementedError("FocalLoss is not built in this package")
+    if task == "classification":
+        if class_weights is not None:
+            raise NotImplementedError("class-weighted classification cross-entropy is not built")
+        return _DeviceCrossEntropy()
+    if task == "segmentation":
+        if loss_type == "dice":
+            return DiceLoss(num_classes=num_classes)
+        if loss_type == "iou":
+            return IoULoss(num_classes=num_classes)
+        return CombinedSegmentationLoss(num_classes=num_classes, weights=class_weights)
+    raise ValueError(f"Unknown task: {task}")

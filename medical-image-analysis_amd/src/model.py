@@ -8,7 +8,7 @@ the MI355X kernels when this package directory is on sys.path in place of founda
 Differences that a caller can observe:
   * the trunk is this package's EfficientNetB3Features (timm is not needed); `pretrained=True`
     cannot download weights (no network) and raises unless MIA_ALLOW_RANDOM_INIT=1 is set;
-  * classification only: segmentation decoders are not part of this hot path and raise;
+  * segmentation heads are the reference's two decoders on this package's kernels (mia_amd.decoders);
   * new optional `compute_dtype` ('fp32' | 'bf16'; config key runtime.dtype), default fp32 as in the reference.
 """
 import logging
@@ -28,6 +28,7 @@ if "mia_amd" not in sys.modules:
     sys.modules["mia_amd"] = _mod
     _spec.loader.exec_module(_mod)
 
+from mia_amd.decoders import EnhancedUNetDecoder, UNetDecoder  # noqa: E402
 from mia_amd.heads import MultiHeadAttentionClassifier, SimpleHead  # noqa: E402
 from mia_amd.trunk import EfficientNetB3Features  # noqa: E402
 
@@ -62,14 +63,18 @@ class FoundationModel(nn.Module):
         for name, n in self.classification_heads.items():
             self.classification_layers[name] = self._make_cls_head(n, dropout)
         self.segmentation_layers = nn.ModuleDict()
-        if self.segmentation_heads:
-            raise NotImplementedError("segmentation decoders are outside this build's hot path "
-                                      f"(requested: {list(self.segmentation_heads)})")
+        for name, n in self.segmentation_heads.items():
+            self.segmentation_layers[name] = self._make_seg_head(n, dropout)
 
     def _make_cls_head(self, num_classes, dropout):
         if self.use_attention:
             return MultiHeadAttentionClassifier(self.feature_dims[-1], self.num_attention_heads, num_classes, dropout)
         return SimpleHead(self.feature_dims[-1], num_classes, dropout)
+
+    def _make_seg_head(self, num_classes, dropout):
+        cls = EnhancedUNetDecoder if self.use_attention else UNetDecoder
+        return cls(encoder_channels=self.feature_dims, decoder_channels=(256, 128, 64, 32, 16),
+                   num_classes=num_classes, dropout=dropout)
 
     def set_compute_dtype(self, dtype):
         self.backbone.compute_dtype = dtype if isinstance(dtype, torch.dtype) else _DTYPES[dtype]
@@ -84,7 +89,8 @@ class FoundationModel(nn.Module):
         elif task == "segmentation":
             if dataset_name not in self.segmentation_layers:
                 raise ValueError(f"Segmentation head for {dataset_name} not found")
-            raise NotImplementedError("segmentation is outside this build's hot path")
+            feats = self.backbone.forward_nhwc(x)
+            return self.segmentation_layers[dataset_name](feats, x.shape[-2:])
         else:
             raise ValueError(f"Unknown task: {task}")
 
@@ -96,28 +102,31 @@ class FoundationModel(nn.Module):
         self.classification_layers[dataset_name] = head.to(device)
 
     def add_segmentation_head(self, dataset_name: str, num_classes: int, dropout: float = 0.2):
-        raise NotImplementedError("segmentation decoders are outside this build's hot path")
+        """model.py:392-414: new decoder on the same device as the model."""
+        self.segmentation_heads[dataset_name] = num_classes
+        head = self._make_seg_head(num_classes, dropout)
+        device = next(self.parameters()).device
+        self.segmentation_layers[dataset_name] = head.to(device)
 
 
 def create_foundation_model(config: dict = None, backbone: str = None, pretrained: bool = None, dropout: float = None,
                             classification_heads: dict = None, segmentation_heads: dict = None,
                             use_attention: bool = None, num_attention_heads: int = None,
                             compute_dtype=None) -> FoundationModel:
-    """model.py:497-546. The config form reads config['model'][...] and the dataset lists; segmentation
-    datasets in the config are ignored with a warning (classification-only build)."""
+    """model.py:497-546. The config form reads config['model'][...] and the two dataset lists."""
     if config is not None:
         classification_heads = {}
         for dc in config.get("classification_datasets", []):
             classification_heads[dc["name"]] = len(dc["classes"])
-        if config.get("segmentation_datasets"):
-            logging.getLogger(__name__).warning(
-                "segmentation datasets %s ignored: segmentation decoders are outside this build's hot path",
-                [d["name"] for d in config["segmentation_datasets"]])
+        segmentation_heads = {}
+        for dc in config.get("segmentation_datasets", []):
+            segmentation_heads[dc["name"]] = dc["num_classes"]
         if compute_dtype is None:
             compute_dtype = (config.get("runtime") or {}).get("dtype")
         return FoundationModel(backbone=config["model"]["backbone"], pretrained=config["model"]["pretrained"],
                                dropout=config["model"]["dropout"], classification_heads=classification_heads,
-                               segmentation_heads={}, use_attention=config["model"].get("use_attention", True),
+                               segmentation_heads=segmentation_heads,
+                               use_attention=config["model"].get("use_attention", True),
                                num_attention_heads=config["model"].get("num_attention_heads", 8),
                                compute_dtype=compute_dtype)
     return FoundationModel(backbone=backbone or "efficientnet-b3",

@@ -77,11 +77,15 @@ def test_factory_reads_reference_config_yaml(tmp_path):
     assert m.classification_heads == {"brain_mri_nd5": 4, "hf_brain_tumor": 4, "pancreas": 2}
     assert m.backbone_name == "efficientnet_b3" and m.use_attention and m.num_attention_heads == 8
     assert m.feature_dims == [24, 32, 48, 136, 384]
-    # trunk + 3 attention heads; with the reference's 5 CBAM-UNet decoders (2,274,021 each) this is the logged
-    # 23,903,135 (training.log:5)
+    # trunk + 3 attention heads + one CBAM-UNet decoder (2,274,021 parameters at 2 classes) per segmentation
+    # dataset; with the reference config's 5 of them this is the logged 23,903,135 (training.log:5)
     n = sum(p.numel() for p in m.parameters())
-    assert n == 10_103_336 + 2 * 810_240 + 809_214
-    assert n + 5 * 2_274_021 == 23_903_135
+    n_seg = len(cfg.get("segmentation_datasets", []))
+    assert set(m.segmentation_layers.keys()) == {d["name"] for d in cfg.get("segmentation_datasets", [])}
+    assert n == 10_103_336 + 2 * 810_240 + 809_214 + sum(
+        2_274_021 + 17 * (d["num_classes"] - 2) for d in cfg.get("segmentation_datasets", []))
+    if n_seg == 5 and all(d["num_classes"] == 2 for d in cfg["segmentation_datasets"]):
+        assert n == 23_903_135
     cfg["runtime"] = {"dtype": "bf16"}
     assert create_foundation_model(config=cfg).backbone.compute_dtype == torch.bfloat16
 
@@ -144,5 +148,12 @@ def test_forward_errors_before_touching_the_device():
         m(x, "detect", "a")
     with pytest.raises(ValueError, match="Segmentation head for a not found"):
         m(x, "segmentation", "a")
-    with pytest.raises(NotImplementedError):
-        FoundationModel(backbone="efficientnet_b3", pretrained=False, segmentation_heads={"s": 2})
+    seg = FoundationModel(backbone="efficientnet_b3", pretrained=False, segmentation_heads={"s": 2})
+    assert type(seg.segmentation_layers["s"]).__name__ == "EnhancedUNetDecoder"
+    keys = list(seg.segmentation_layers["s"].state_dict().keys())
+    assert keys[0] == "decoder_blocks.0.conv1.weight" and keys[-1] == "final_conv.bias"
+    assert "cbam_modules.4.SpatialGate.spatial.bn.running_var" in keys
+    plain = FoundationModel(backbone="efficientnet_b3", pretrained=False, segmentation_heads={"s": 2}, use_attention=False)
+    assert type(plain.segmentation_layers["s"]).__name__ == "UNetDecoder"
+    with pytest.raises(RuntimeError):      # no device, no fallback
+        seg(x, "segmentation", "s")
