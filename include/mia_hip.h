@@ -116,10 +116,15 @@ int mia_se_bn_combine(const float* sums, int B, int splits, int C, const float* 
 
 /* ---- CBAM (src/model.py:28-108) on an NHWC feature map x [B,H*W,C] -----------------------------------------
  * channel gate (ChannelGate, model.py:45-67): avg/max pool over H*W, shared MLP C->HID->C (ReLU) on both, sum,
- * sigmoid -> cscale [B,C]. avg, mx, amax (arg-max pixel), ha, hm (hidden activations) are kept for the backward. */
+ * sigmoid -> cscale [B,C]. avg, mx, amax (arg-max pixel), ha, hm (hidden activations) are kept for the backward.
+ * ws: fp32 scratch of mia_cbam_ws_floats(B, H, W, C, HID, 0) floats (0 for small maps: ws may be NULL then). */
 int mia_cbam_channel_fwd(int dtype, const void* x, int B, int HW, int C, int HID, const float* W1, const float* b1,
                          const float* W2, const float* b2, float* avg, float* mx, int* amax, float* ha, float* hm,
-                         float* cscale, void* stream);
+                         float* cscale, float* ws, void* stream);
+/* Workspace size in floats of the CBAM forward (backward = 0) or backward (backward = 1) for this shape; returns a
+ * count, not an error code (-1 if it does not fit an int). Large maps (the decoder levels of
+ * EnhancedUNetDecoder, model.py:211) split their per-image reductions over row ranges and need room for partials. */
+int mia_cbam_ws_floats(int B, int H, int W, int C, int HID, int backward);
 /* spatial gate, first half (ChannelPool + 7x7 conv, model.py:77-91): comp [B,HW,2] = (max_c, mean_c) of x*cscale,
  * cmax = arg-max channel, pre = conv7x7(comp) (w7 [2][7][7]); part [part_rows][2][1] feeds mia_bn_finalize_fwd (C=1). */
 int mia_cbam_spatial_fwd(int dtype, const void* x, const float* cscale, int B, int H, int W, int C, const float* w7,
@@ -128,7 +133,7 @@ int mia_cbam_spatial_fwd(int dtype, const void* x, const float* cscale, int B, i
 int mia_cbam_apply(int dtype, const void* x, const float* cscale, const float* pre, const float* bnst, int B, int HW,
                    int C, void* out, float* sgate, void* stream);
 /* Backward of the whole CBAM module. bnst = {scale, shift, mean, rstd} of the BatchNorm(1); ws: fp32 scratch of
- * 4*B*H*W + 4*B*C + 2*B*HID floats. */
+ * mia_cbam_ws_floats(B, H, W, C, HID, 1) floats. */
 int mia_cbam_bwd(int dtype, const void* dx2, const void* x, int B, int H, int W, int C, int HID, const float* cscale,
                  const float* sgate, const float* pre, const float* bnst, const float* bn_gamma, int bn_training,
                  const float* comp, const int* cmax, const int* amax, const float* avg, const float* mx,

@@ -40,6 +40,68 @@ __global__ __launch_bounds__(256) void cbam_channel_pool_kernel(const T* x, int 
     amax[(size_t)b * C + c] = am;
 }
 
+// The same pooling for large maps (decoder levels: up to 150x150 pixels, few channels): one workgroup per
+// (image, row split), 256 threads = row lanes x 4-channel lanes, then a per-image combine that keeps the FIRST
+// arg-max in row order (what max_pool2d's backward uses).
+template <typename T>
+__global__ __launch_bounds__(256) void cbam_channel_pool_split_kernel(const T* x, int HW, int C, int splits,
+                                                                      float* psum, float* pmax, int* parg) {
+    __shared__ f4 rs[256];
+    __shared__ f4 rm[256];
+    __shared__ int ra[256][4];
+    const int tid = threadIdx.x, cvn = C >> 2, npl = 256 / cvn;
+    const int cvl = tid % cvn, pl = tid / cvn;
+    const int b = blockIdx.x / splits, sp = blockIdx.x % splits;
+    const int per = (HW + splits - 1) / splits;
+    const int r0 = sp * per, r1 = (r0 + per) < HW ? (r0 + per) : HW;
+    f4 s = {0.f, 0.f, 0.f, 0.f}, m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int a0 = r0, a1 = r0, a2 = r0, a3 = r0;
+    if (pl < npl)
+        for (int r = r0 + pl; r < r1; r += npl) {
+            const f4 v = load4<T>(x + ((size_t)b * HW + r) * C + cvl * 4);
+            s = {s.x + v.x, s.y + v.y, s.z + v.z, s.w + v.w};
+            if (v.x > m.x) { m.x = v.x; a0 = r; }
+            if (v.y > m.y) { m.y = v.y; a1 = r; }
+            if (v.z > m.z) { m.z = v.z; a2 = r; }
+            if (v.w > m.w) { m.w = v.w; a3 = r; }
+        }
+    rs[tid] = s; rm[tid] = m;
+    ra[tid][0] = a0; ra[tid][1] = a1; ra[tid][2] = a2; ra[tid][3] = a3;
+    __syncthreads();
+    if (tid < cvn) {
+        for (int q = 1; q < npl; ++q) {
+            const int o = q * cvn + tid;
+            const f4 os = rs[o], om = rm[o];
+            s = {s.x + os.x, s.y + os.y, s.z + os.z, s.w + os.w};
+            if (om.x > m.x || (om.x == m.x && ra[o][0] < a0)) { m.x = om.x; a0 = ra[o][0]; }
+            if (om.y > m.y || (om.y == m.y && ra[o][1] < a1)) { m.y = om.y; a1 = ra[o][1]; }
+            if (om.z > m.z || (om.z == m.z && ra[o][2] < a2)) { m.z = om.z; a2 = ra[o][2]; }
+            if (om.w > m.w || (om.w == m.w && ra[o][3] < a3)) { m.w = om.w; a3 = ra[o][3]; }
+        }
+        const size_t o = ((size_t)b * splits + sp) * C + tid * 4;
+        store4<float>(psum + o, s);
+        store4<float>(pmax + o, m);
+        parg[o] = a0; parg[o + 1] = a1; parg[o + 2] = a2; parg[o + 3] = a3;
+    }
+}
+
+__global__ __launch_bounds__(256) void cbam_channel_pool_combine_kernel(const float* psum, const float* pmax,
+                                                                        const int* parg, int HW, int C, int splits,
+                                                                        float* avg, float* mx, int* amax) {
+    const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, m = -INFINITY;
+    int am = 0;
+    for (int sp = 0; sp < splits; ++sp) {   // splits are in row order: strict > keeps the first arg-max
+        const size_t o = ((size_t)b * splits + sp) * C + c;
+        s += psum[o];
+        if (pmax[o] > m) { m = pmax[o]; am = parg[o]; }
+    }
+    avg[(size_t)b * C + c] = s / (float)HW;
+    mx[(size_t)b * C + c] = m;
+    amax[(size_t)b * C + c] = am;
+}
+
 // shared MLP C -> HID -> C on both pooled vectors, summed, sigmoid. One workgroup per image.
 __global__ __launch_bounds__(256) void cbam_channel_mlp_kernel(const float* avg, const float* mx, int C, int HID,
                                                                const float* W1, const float* b1, const float* W2,
@@ -213,14 +275,66 @@ __global__ __launch_bounds__(1024) void cbam_bwd_spatial_bn_kernel(const float* 
     if (tid == 0) { dgamma[0] = Q; dbeta[0] = S; }
 }
 
-// weight gradient of the 7x7 conv: dw[ch][kh][kw] = sum_{b,y,x} dpre[b,y,x] * comp[b,y+kh-3,x+kw-3,ch]. grid = 98.
+// The same in two launches for large N: per-workgroup partial sums, then every workgroup folds the partials and
+// applies the formula to its own slice.
+__global__ __launch_bounds__(256) void cbam_bwd_spatial_bn_part_kernel(const float* dsg, const float* sgate,
+                                                                       const float* pre, const float* st, long long N,
+                                                                       float* part) {
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x;
+    const float mean = st[2], rstd = st[3];
+    float s = 0.f, q = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < N; i += (long long)gridDim.x * 256) {
+        const float sg = sgate[i];
+        const float g = dsg[i] * sg * (1.f - sg);
+        s += g;
+        q += g * ((pre[i] - mean) * rstd);
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        part[blockIdx.x * 2 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        part[blockIdx.x * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+__global__ __launch_bounds__(256) void cbam_bwd_spatial_bn_apply_kernel(const float* dsg, const float* sgate,
+                                                                        const float* pre, const float* st,
+                                                                        const float* gamma, int training, long long N,
+                                                                        const float* part, int nparts, float* dpre,
+                                                                        float* dgamma, float* dbeta) {
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x;
+    float s = 0.f, q = 0.f;
+    for (int k = tid; k < nparts; k += 256) { s += part[k * 2 + 0]; q += part[k * 2 + 1]; }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = q; }
+    __syncthreads();
+    const float S = red[0][0] + red[0][1] + red[0][2] + red[0][3], Q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const float mean = st[2], rstd = st[3], ga = gamma[0], invn = 1.0f / (float)N;
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < N; i += (long long)gridDim.x * 256) {
+        const float sg = sgate[i];
+        const float g = dsg[i] * sg * (1.f - sg);
+        const float xh = (pre[i] - mean) * rstd;
+        dpre[i] = training ? ga * rstd * (g - S * invn - xh * Q * invn) : ga * rstd * g;
+    }
+    if (blockIdx.x == 0 && tid == 0) { dgamma[0] = Q; dbeta[0] = S; }
+}
+
+// weight gradient of the 7x7 conv: dw[ch][kh][kw] = sum_{b,y,x} dpre[b,y,x] * comp[b,y+kh-3,x+kw-3,ch].
+// grid = (98 taps, pixel chunks); chunk partials land in out[chunk][98].
 __global__ __launch_bounds__(256) void cbam_bwd_conv_weight_kernel(const float* dpre, const float* comp, int B, int H,
-                                                                   int W, float* dw7) {
+                                                                   int W, float* out) {
     __shared__ float red[4];
     const int tap = blockIdx.x, ch = tap / 49, kh = (tap % 49) / 7, kw = tap % 7;
     const long long total = (long long)B * H * W;
+    const long long per = (total + gridDim.y - 1) / gridDim.y;
+    const long long i0 = (long long)blockIdx.y * per, i1 = (i0 + per) < total ? (i0 + per) : total;
     float s = 0.f;
-    for (long long i = threadIdx.x; i < total; i += 256) {
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
         const int xw = (int)(i % W), yh = (int)((i / W) % H);
         const long long b = i / ((long long)W * H);
         const int ih = yh + kh - 3, iw = xw + kw - 3;
@@ -229,7 +343,15 @@ __global__ __launch_bounds__(256) void cbam_bwd_conv_weight_kernel(const float* 
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) dw7[tap] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) out[(size_t)blockIdx.y * 98 + tap] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(128) void cbam_bwd_conv_weight_fold_kernel(const float* part, int chunks, float* dw7) {
+    const int tap = threadIdx.x;
+    if (tap >= 98) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += part[(size_t)k * 98 + tap];
+    dw7[tap] = s;
 }
 
 // dcomp[b,p,ch] = sum_taps dpre[b, p - tap] * w[ch][tap]  (data gradient of the 7x7 conv)
@@ -278,9 +400,45 @@ __global__ __launch_bounds__(256) void cbam_bwd_dcs_kernel(const T* dx2, const T
     dcs[(size_t)b * C + c] = s;
 }
 
-// channel-MLP backward for one image: datt, dpre_a, dpre_m kept for the parameter gradients; davg, dmax out
-__global__ __launch_bounds__(256) void cbam_bwd_mlp_kernel(const float* dcs, const float* cscale, const float* ha,
-                                                           const float* hm, int C, int HID, const float* W1,
+// The same for large maps: one workgroup per (image, row split); dcs_part[b][split][c].
+template <typename T>
+__global__ __launch_bounds__(256) void cbam_bwd_dcs_split_kernel(const T* dx2, const T* x, const float* sgate,
+                                                                 const float* dcomp, const int* cmax, int HW, int C,
+                                                                 int splits, float* dcs_part) {
+    __shared__ f4 rs[256];
+    const int tid = threadIdx.x, cvn = C >> 2, npl = 256 / cvn;
+    const int cvl = tid % cvn, pl = tid / cvn, c = cvl * 4;
+    const int b = blockIdx.x / splits, sp = blockIdx.x % splits;
+    const int per = (HW + splits - 1) / splits;
+    const int r0 = sp * per, r1 = (r0 + per) < HW ? (r0 + per) : HW;
+    const float invc = 1.0f / (float)C;
+    f4 s = {0.f, 0.f, 0.f, 0.f};
+    if (pl < npl)
+        for (int r = r0 + pl; r < r1; r += npl) {
+            const size_t pix = (size_t)b * HW + r;
+            const f4 g = load4<T>(dx2 + pix * C + c), v = load4<T>(x + pix * C + c);
+            const float sg = sgate[pix], dm = dcomp[pix * 2 + 1] * invc, dmx = dcomp[pix * 2 + 0];
+            const int cm = cmax[pix] - c;
+            s.x += (g.x * sg + dm + (cm == 0 ? dmx : 0.f)) * v.x;
+            s.y += (g.y * sg + dm + (cm == 1 ? dmx : 0.f)) * v.y;
+            s.z += (g.z * sg + dm + (cm == 2 ? dmx : 0.f)) * v.z;
+            s.w += (g.w * sg + dm + (cm == 3 ? dmx : 0.f)) * v.w;
+        }
+    rs[tid] = s;
+    __syncthreads();
+    if (tid < cvn) {
+        for (int q = 1; q < npl; ++q) {
+            const f4 o = rs[q * cvn + tid];
+            s = {s.x + o.x, s.y + o.y, s.z + o.z, s.w + o.w};
+        }
+        store4<float>(dcs_part + ((size_t)b * splits + sp) * C + c, s);
+    }
+}
+
+// channel-MLP backward for one image: datt, dpre_a, dpre_m (dcs summed over its row splits) kept for the parameter gradients; davg, dmax out
+__global__ __launch_bounds__(256) void cbam_bwd_mlp_kernel(const float* dcs, int splits, const float* cscale,
+                                                           const float* ha, const float* hm, int C, int HID,
+                                                           const float* W1,
                                                            const float* W2, float* datt, float* dpa, float* dpm,
                                                            float* davg, float* dmax) {
     extern __shared__ float sm[];
@@ -290,7 +448,9 @@ __global__ __launch_bounds__(256) void cbam_bwd_mlp_kernel(const float* dcs, con
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int c = tid; c < C; c += 256) {
         const float cs = cscale[(size_t)b * C + c];
-        const float v = dcs[(size_t)b * C + c] * cs * (1.f - cs);
+        float d = 0.f;
+        for (int sp = 0; sp < splits; ++sp) d += dcs[((size_t)b * splits + sp) * C + c];
+        const float v = d * cs * (1.f - cs);
         da[c] = v;
         datt[(size_t)b * C + c] = v;
     }
@@ -655,16 +815,55 @@ static inline unsigned grid1d(long long n, int per = 256, long long cap = 16384)
     return (unsigned)b;
 }
 
+// Row splits per image for the pooled reductions of a map with HW pixels: about 1024 workgroups in total, at
+// least 64 rows each; 1 = the one-thread-per-channel kernels (small maps, or more than 1024 channels).
+static int cbam_row_splits(int B, int HW, int C) {
+    if (C % 4 != 0 || C / 4 > 256) return 1;
+    int s = HW / 64, cap = 1024 / B;
+    if (cap < 1) cap = 1;
+    if (s > cap) s = cap;
+    return s < 2 ? 1 : s;
+}
+static int cbam_bn_parts(long long npix) { return npix > 32768 ? (int)((npix + 4095) / 4096 > 256 ? 256 : (npix + 4095) / 4096) : 0; }
+static int cbam_conv_chunks(long long npix) { return npix > 32768 ? (int)((npix + 8191) / 8192 > 64 ? 64 : (npix + 8191) / 8192) : 1; }
+
+extern "C" int mia_cbam_ws_floats(int B, int H, int W, int C, int HID, int backward) {
+    const long long npix = (long long)B * H * W;
+    const int splits = cbam_row_splits(B, H * W, C);
+    long long n;
+    if (!backward) n = splits > 1 ? 3LL * B * splits * C : 0;
+    else
+        n = 4 * npix + 4LL * B * C + 2LL * B * HID + (splits > 1 ? (long long)B * splits * C : 0) +
+            2LL * cbam_bn_parts(npix) + (cbam_conv_chunks(npix) > 1 ? 98LL * cbam_conv_chunks(npix) : 0);
+    return n > 0x7fffffffLL ? -1 : (int)n;
+}
+
 extern "C" int mia_cbam_channel_fwd(int dtype, const void* x, int B, int HW, int C, int HID, const float* W1,
                                     const float* b1, const float* W2, const float* b2, float* avg, float* mx,
-                                    int* amax, float* ha, float* hm, float* cscale, void* stream) {
+                                    int* amax, float* ha, float* hm, float* cscale, float* ws, void* stream) {
     MIA_CHECK_ARG(x && W1 && b1 && W2 && b2 && avg && mx && amax && ha && hm && cscale, "mia_cbam_channel_fwd: null");
     MIA_CHECK_ARG(B > 0 && HW > 0 && C > 0 && HID > 0, "mia_cbam_channel_fwd: bad shape");
-    dim3 g(B, cdiv(C, 256));
-    if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(cbam_channel_pool_kernel<bf16_t>, g, dim3(256), 0, MIA_STREAM, (const bf16_t*)x, HW, C, avg, mx, amax);
-    else
-        hipLaunchKernelGGL(cbam_channel_pool_kernel<float>, g, dim3(256), 0, MIA_STREAM, (const float*)x, HW, C, avg, mx, amax);
+    const int splits = cbam_row_splits(B, HW, C);
+    if (splits > 1) {
+        MIA_CHECK_ARG(ws, "mia_cbam_channel_fwd: this shape needs the workspace of mia_cbam_ws_floats");
+        float* psum = ws;
+        float* pmax = psum + (size_t)B * splits * C;
+        int* parg = reinterpret_cast<int*>(pmax + (size_t)B * splits * C);
+        if (dtype == MIA_BF16)
+            hipLaunchKernelGGL(cbam_channel_pool_split_kernel<bf16_t>, dim3(B * splits), dim3(256), 0, MIA_STREAM,
+                               (const bf16_t*)x, HW, C, splits, psum, pmax, parg);
+        else
+            hipLaunchKernelGGL(cbam_channel_pool_split_kernel<float>, dim3(B * splits), dim3(256), 0, MIA_STREAM,
+                               (const float*)x, HW, C, splits, psum, pmax, parg);
+        hipLaunchKernelGGL(cbam_channel_pool_combine_kernel, dim3(B, cdiv(C, 256)), dim3(256), 0, MIA_STREAM, psum, pmax,
+                           parg, HW, C, splits, avg, mx, amax);
+    } else {
+        dim3 g(B, cdiv(C, 256));
+        if (dtype == MIA_BF16)
+            hipLaunchKernelGGL(cbam_channel_pool_kernel<bf16_t>, g, dim3(256), 0, MIA_STREAM, (const bf16_t*)x, HW, C, avg, mx, amax);
+        else
+            hipLaunchKernelGGL(cbam_channel_pool_kernel<float>, g, dim3(256), 0, MIA_STREAM, (const float*)x, HW, C, avg, mx, amax);
+    }
     hipLaunchKernelGGL(cbam_channel_mlp_kernel, dim3(B), dim3(256), (size_t)(2 * C + HID) * 4, MIA_STREAM, avg, mx, C, HID,
                        W1, b1, W2, b2, ha, hm, cscale);
     MIA_CHECK_LAUNCH("mia_cbam_channel_fwd");
@@ -704,7 +903,7 @@ extern "C" int mia_cbam_apply(int dtype, const void* x, const float* cscale, con
     return 0;
 }
 
-// full CBAM backward. ws: fp32 scratch of at least 4*B*H*W + 4*B*C + 2*B*HID floats.
+// full CBAM backward. ws: fp32 scratch of mia_cbam_ws_floats(B, H, W, C, HID, 1) floats.
 extern "C" int mia_cbam_bwd(int dtype, const void* dx2, const void* x, int B, int H, int W, int C, int HID,
                             const float* cscale, const float* sgate, const float* pre, const float* bnst,
                             const float* bn_gamma, int bn_training, const float* comp, const int* cmax,
@@ -727,6 +926,10 @@ extern "C" int mia_cbam_bwd(int dtype, const void* dx2, const void* x, int B, in
     float* dmax = davg + (size_t)B * C;   // caller sized ws for 4*npix + 4*B*C + 2*B*HID
     float* dpa = dmax + (size_t)B * C;
     float* dpm = dpa + (size_t)B * HID;
+    const int splits = cbam_row_splits(B, HW, C), bn_parts = cbam_bn_parts(npix), chunks = cbam_conv_chunks(npix);
+    float* dcs_part = dpm + (size_t)B * HID;                                   // [B][splits][C] when splits > 1
+    float* bn_part = dcs_part + (splits > 1 ? (size_t)B * splits * C : 0);      // [bn_parts][2]
+    float* cw_part = bn_part + 2 * (size_t)bn_parts;                            // [chunks][98] when chunks > 1
     hipStream_t s = MIA_STREAM;
     const unsigned gp = (unsigned)((npix + 3) / 4);
     if (dtype == MIA_BF16)
@@ -735,19 +938,37 @@ extern "C" int mia_cbam_bwd(int dtype, const void* dx2, const void* x, int B, in
     else
         hipLaunchKernelGGL(cbam_bwd_dsgate_kernel<float>, dim3(gp), dim3(256), 0, s, (const float*)dx2, (const float*)x,
                            cscale, B, HW, C, dsg);
-    hipLaunchKernelGGL(cbam_bwd_spatial_bn_kernel, dim3(1), dim3(1024), 0, s, dsg, sgate, pre, bnst, bn_gamma,
-                       bn_training, npix, dpre, dbn_gamma, dbn_beta);
-    hipLaunchKernelGGL(cbam_bwd_conv_weight_kernel, dim3(98), dim3(256), 0, s, dpre, comp, B, H, W, dw7);
+    if (bn_parts > 0) {
+        hipLaunchKernelGGL(cbam_bwd_spatial_bn_part_kernel, dim3(bn_parts), dim3(256), 0, s, dsg, sgate, pre, bnst, npix,
+                           bn_part);
+        hipLaunchKernelGGL(cbam_bwd_spatial_bn_apply_kernel, dim3(grid1d(npix, 1024)), dim3(256), 0, s, dsg, sgate, pre,
+                           bnst, bn_gamma, bn_training, npix, bn_part, bn_parts, dpre, dbn_gamma, dbn_beta);
+    } else {
+        hipLaunchKernelGGL(cbam_bwd_spatial_bn_kernel, dim3(1), dim3(1024), 0, s, dsg, sgate, pre, bnst, bn_gamma,
+                           bn_training, npix, dpre, dbn_gamma, dbn_beta);
+    }
+    hipLaunchKernelGGL(cbam_bwd_conv_weight_kernel, dim3(98, chunks), dim3(256), 0, s, dpre, comp, B, H, W,
+                       chunks > 1 ? cw_part : dw7);
+    if (chunks > 1) hipLaunchKernelGGL(cbam_bwd_conv_weight_fold_kernel, dim3(1), dim3(128), 0, s, cw_part, chunks, dw7);
     hipLaunchKernelGGL(cbam_bwd_conv_data_kernel, dim3(grid1d(npix)), dim3(256), 0, s, dpre, B, H, W, w7, dcomp);
-    dim3 gc(B, cdiv(C, 256));
-    if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(cbam_bwd_dcs_kernel<bf16_t>, gc, dim3(256), 0, s, (const bf16_t*)dx2, (const bf16_t*)x, sgate,
-                           dcomp, cmax, HW, C, dcs);
-    else
-        hipLaunchKernelGGL(cbam_bwd_dcs_kernel<float>, gc, dim3(256), 0, s, (const float*)dx2, (const float*)x, sgate, dcomp,
-                           cmax, HW, C, dcs);
-    hipLaunchKernelGGL(cbam_bwd_mlp_kernel, dim3(B), dim3(256), (size_t)(C + 2 * HID) * 4, s, dcs, cscale, ha, hm, C, HID, W1,
-                       W2, datt, dpa, dpm, davg, dmax);
+    if (splits > 1) {
+        if (dtype == MIA_BF16)
+            hipLaunchKernelGGL(cbam_bwd_dcs_split_kernel<bf16_t>, dim3(B * splits), dim3(256), 0, s, (const bf16_t*)dx2,
+                               (const bf16_t*)x, sgate, dcomp, cmax, HW, C, splits, dcs_part);
+        else
+            hipLaunchKernelGGL(cbam_bwd_dcs_split_kernel<float>, dim3(B * splits), dim3(256), 0, s, (const float*)dx2,
+                               (const float*)x, sgate, dcomp, cmax, HW, C, splits, dcs_part);
+    } else {
+        dim3 gc(B, cdiv(C, 256));
+        if (dtype == MIA_BF16)
+            hipLaunchKernelGGL(cbam_bwd_dcs_kernel<bf16_t>, gc, dim3(256), 0, s, (const bf16_t*)dx2, (const bf16_t*)x, sgate,
+                               dcomp, cmax, HW, C, dcs);
+        else
+            hipLaunchKernelGGL(cbam_bwd_dcs_kernel<float>, gc, dim3(256), 0, s, (const float*)dx2, (const float*)x, sgate,
+                               dcomp, cmax, HW, C, dcs);
+    }
+    hipLaunchKernelGGL(cbam_bwd_mlp_kernel, dim3(B), dim3(256), (size_t)(C + 2 * HID) * 4, s, splits > 1 ? dcs_part : dcs,
+                       splits > 1 ? splits : 1, cscale, ha, hm, C, HID, W1, W2, datt, dpa, dpm, davg, dmax);
     hipLaunchKernelGGL(cbam_bwd_mlp_param_kernel, dim3(cdiv((long long)C * HID, 256)), dim3(256), 0, s, B, C, HID, datt, dpa,
                        dpm, ha, hm, avg, mx, dW1, db1, dW2, db2);
     const unsigned ge = grid1d((long long)B * HW * C);

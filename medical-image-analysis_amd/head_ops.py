@@ -34,12 +34,14 @@ class CBAMFn(torch.autograd.Function):
         avg, mx, cscale = (torch.empty((B, C), **f32) for _ in range(3))
         amax = torch.empty((B, C), dtype=torch.int32, device=dev)
         ha, hm = torch.empty((B, HID), **f32), torch.empty((B, HID), **f32)
+        nws = lib().mia_cbam_ws_floats(B, H, W, C, HID, 0)
+        ws = torch.empty((nws,), **f32) if nws > 0 else None
         lib().mia_cbam_channel_fwd(_DT[x.dtype], _p(x), B, HW, C, HID, _p(W1), _p(b1), _p(W2), _p(b2), _p(avg), _p(mx),
-                                   _p(amax), _p(ha), _p(hm), _p(cscale), _stream())
+                                   _p(amax), _p(ha), _p(hm), _p(cscale), _p(ws), _stream())
         comp = torch.empty((B, HW, 2), **f32)
         cmax = torch.empty((B, HW), dtype=torch.int32, device=dev)
         pre = torch.empty((B, HW), **f32)
-        rows = max(1, min(64, (B * HW + 255) // 256))
+        rows = max(1, min(1024, (B * HW + 255) // 256))
         part = torch.empty((rows, 2, 1), **f32)
         w7c = w7.detach().reshape(2, 49).contiguous()
         lib().mia_cbam_spatial_fwd(_DT[x.dtype], _p(x), _p(cscale), B, H, W, C, _p(w7c), _p(comp), _p(cmax), _p(pre),
@@ -59,7 +61,10 @@ class CBAMFn(torch.autograd.Function):
         B, H, W, C = x.shape
         HID, dev = W1.shape[0], x.device
         f32 = dict(dtype=torch.float32, device=dev)
-        ws = torch.empty((4 * B * H * W + 4 * B * C + 2 * B * HID,), **f32)
+        nws = lib().mia_cbam_ws_floats(B, H, W, C, HID, 1)
+        if nws < 0:
+            raise ValueError("CBAM backward workspace does not fit: reduce the batch")
+        ws = torch.empty((nws,), **f32)
         dx = torch.empty_like(x)
         dW1, db1 = torch.empty_like(W1), torch.empty((HID,), **f32)
         dW2, db2 = torch.empty_like(W2), torch.empty((C,), **f32)

@@ -169,7 +169,8 @@ class _ChannelGate(nn.Module):
         self.mlp = nn.Sequential(_Flatten(), nn.Linear(c, c // r), nn.ReLU(), nn.Linear(c // r, c))
 
     def forward(self, x):
-        a = self.mlp(x.mean((2, 3))) + self.mlp(x.amax((2, 3)))
+        # max_pool2d, not amax: on ties its backward routes the whole gradient to the first maximum (model.py:52)
+        a = self.mlp(x.mean((2, 3))) + self.mlp(F.max_pool2d(x, (x.size(2), x.size(3))))
         return x * torch.sigmoid(a)[:, :, None, None]
 
 
@@ -179,7 +180,8 @@ class _SpatialGate(nn.Module):
         self.spatial = _BasicConv()
 
     def forward(self, x):
-        comp = torch.cat((x.amax(1, keepdim=True), x.mean(1, keepdim=True)), dim=1)
+        # torch.max(x, 1)[0] as at model.py:79: ties send the gradient to the first maximal channel
+        comp = torch.cat((x.max(1, keepdim=True)[0], x.mean(1, keepdim=True)), dim=1)
         return x * torch.sigmoid(self.spatial(comp))
 
 
@@ -228,10 +230,10 @@ def simple_head(feature_dim, num_classes, dropout=0.2):
 
 
 class OracleFoundationModel(nn.Module):
-    """FoundationModel (model.py:240-363), classification task only."""
+    """FoundationModel (model.py:240-363): trunk + classification heads + segmentation decoders."""
 
     def __init__(self, classification_heads: Optional[Dict[str, int]] = None, dropout=0.2,
-                 use_attention=True, num_attention_heads=8):
+                 use_attention=True, num_attention_heads=8, segmentation_heads: Optional[Dict[str, int]] = None):
         super().__init__()
         self.backbone = EfficientNetB3Features()
         self.feature_dims = list(B3_FEATURE_DIMS)
@@ -242,9 +244,19 @@ class OracleFoundationModel(nn.Module):
                     self.feature_dims[-1], num_attention_heads, n, dropout)
             else:
                 self.classification_layers[name] = simple_head(self.feature_dims[-1], n, dropout)
+        self.segmentation_layers = nn.ModuleDict()
+        if segmentation_heads:
+            from . import seg_ref
+            cls = seg_ref.EnhancedUNetDecoder if use_attention else seg_ref.UNetDecoder
+            for name, n in segmentation_heads.items():
+                self.segmentation_layers[name] = cls(self.feature_dims, num_classes=n, dropout=dropout)
 
     def forward(self, x, task, dataset_name):
         feats = self.backbone(x)
+        if task == "segmentation":
+            if dataset_name not in self.segmentation_layers:
+                raise ValueError(f"Segmentation head for {dataset_name} not found")
+            return self.segmentation_layers[dataset_name](feats, x.shape[-2:])
         if task != "classification":
             raise ValueError(f"Unknown task: {task}")
         if dataset_name not in self.classification_layers:

@@ -227,3 +227,71 @@ def test_foundation_model_segmentation_path():
     model.eval()
     with torch.no_grad():
         assert model(x, "segmentation", "seg").shape == (2, 2, 72, 72)
+
+
+@pytest.mark.parametrize("use_attention", [True, False])
+def test_segmentation_step_matches_oracle_fp32(use_attention):
+    """Whole model, segmentation task: trunk + decoder + combined loss, one forward/backward at 96x96, batch 4,
+    train-mode BatchNorm, dropout 0, against the CPU oracle with the same seeded state dict."""
+    from oracle import effnet_b3 as O
+    from oracle import seg_ref as S
+    from seeding import seeded_state_dict
+    from mia_amd.src.loss import get_loss_function
+    from mia_amd.src.model import FoundationModel, load_model_weights_safely
+    ref = O.OracleFoundationModel({}, dropout=0.0, use_attention=use_attention, segmentation_heads={"seg": 3})
+    sd = seeded_state_dict(ref, 5)
+    ref.load_state_dict(sd)
+    mine = FoundationModel(backbone="efficientnet_b3", pretrained=False, dropout=0.0, classification_heads={},
+                           segmentation_heads={"seg": 3}, use_attention=use_attention)
+    missing, unexpected = load_model_weights_safely(mine, {"model_state_dict": sd})
+    assert not missing and not unexpected
+    mine = mine.cuda().train()
+    ref.train()
+    x = randn(200, 4, 3, 96, 96)
+    t = torch.from_numpy(np.random.default_rng(9).integers(0, 3, (4, 96, 96)))
+    lr = ref(x, "segmentation", "seg")
+    loss_r = S.combined_segmentation_loss(lr, t, 3)
+    loss_r.backward()
+    lm = mine(x.cuda(), "segmentation", "seg")
+    loss_m = get_loss_function("segmentation", num_classes=3)(lm, t.cuda())
+    loss_m.backward()
+    assert rel(lm, lr) < 1e-4
+    assert abs(loss_m.item() - loss_r.item()) < 1e-5 * max(1.0, abs(loss_r.item()))
+    pr = dict(ref.named_parameters())
+    rows = []
+    for n, p in mine.named_parameters():
+        assert p.grad is not None, n
+        a, b = p.grad.detach().double().cpu(), pr[n].grad.detach().double()
+        rows.append(((a - b).abs().max().item(), b.abs().max().item(), n))
+    scale = {n: m for _, m, n in rows}
+    worst = (0.0, "")
+    for err, mag, n in rows:
+        # parameters whose true gradient is exactly zero (a shift removed by the next train-mode BatchNorm) hold
+        # rounding noise on both sides: compare them against the gradient scale of the same layer's weight
+        if n.endswith(".bias") and ((".bn" in n and "backbone" in n) or "decoder_blocks" in n and ".conv" in n):
+            mag = max(mag, scale[n[:-4] + "weight"])
+        worst = max(worst, (err / max(mag, 1e-30), n))
+    assert worst[0] < 2e-3, worst
+
+
+@pytest.mark.parametrize("c,h,w", [(16, 48, 48), (32, 75, 75), (256, 19, 19), (64, 40, 33)])
+@pytest.mark.parametrize("train", [True, False])
+def test_cbam_large_map_matches_oracle(c, h, w, train):
+    """Decoder-level CBAM shapes take the row-split reduction kernels; the oracle's CBAM (itself pinned to the
+    reference's by the small goldens) is the checker. ReLU-like inputs (many exact zeros and ties) included."""
+    from oracle import effnet_b3 as O
+    from mia_amd.heads import CBAM
+    ref = load_seeded(O.CBAM(c), 81).train(train)
+    mine = load_seeded(CBAM(c), 81).cuda().train(train)
+    x = torch.relu(randn(82, 2, c, h, w))
+    xr = x.clone().requires_grad_(True)
+    xm = nhwc(x).cuda().requires_grad_(True)
+    out_r, out_m = ref(xr), mine(xm)
+    assert rel(out_m.permute(0, 3, 1, 2), out_r) < 1e-4
+    g = randn(83, 2, c, h, w)
+    out_r.backward(g)
+    out_m.backward(nhwc(g).cuda())
+    assert rel(xm.grad.permute(0, 3, 1, 2), xr.grad) < 1e-3
+    pr = dict(ref.named_parameters())
+    for k, p in mine.named_parameters():
+        assert rel(p.grad, pr[k].grad) < 1e-3, k
