@@ -73,10 +73,11 @@ int mia_bn_finalize_fwd(const float* part, int P, int C, double count, const flo
                         float eps, int training, const float* conv_bias, float* scale, float* shift, float* mean,
                         float* rstd, void* stream);
 /* part holds partials of (sum g, sum g*xhat). Outputs dgamma, dbeta (nullable) and the coefficients of
- * dy = ca*g + cb*y + cd (y = raw pre-BN tensor). */
+ * dy = ca*g + cb*y + cd (y = raw pre-BN tensor). dconv_bias (nullable): gradient of a convolution bias added before
+ * this normalisation (= column sum of dy: zero with batch statistics, ca * sum g with running statistics). */
 int mia_bn_finalize_bwd(const float* part, int P, int C, double count, const float* gamma, const float* mean,
                         const float* rstd, int training, float* dgamma, float* dbeta, float* ca, float* cb, float* cd,
-                        void* stream);
+                        float* dconv_bias, void* stream);
 /* g = (G*gate[b] + dpool[b]) * act'(Y*scale+shift) written over G (b = row / rows_per_img; gate, dpool optional);
  * part <- partials of sum(g), sum(g*(Y-mean)*rstd). */
 int mia_bn_act_bwd_reduce(int dtype, void* G, const void* Y, long long R, int C, const float* scale,

@@ -125,7 +125,7 @@ extern "C" int mia_bn_finalize_fwd(const float* part, int P, int C, double count
 __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* part, int P, int C, double count,
                                                               const float* gamma, const float* mean, const float* rstd,
                                                               int training, float* dgamma, float* dbeta, float* ca,
-                                                              float* cb, float* cd) {
+                                                              float* cb, float* cd, float* dconv_bias) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 4 + wave;
     if (c >= C) return;
@@ -144,6 +144,8 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* part,
         const double rs = rstd[c], mu = mean[c];
         if (dgamma) dgamma[c] = (float)q;
         if (dbeta) dbeta[c] = (float)s;
+        // gradient of a bias added before the normalisation = column sum of dy: exactly zero with batch statistics
+        if (dconv_bias) dconv_bias[c] = training ? 0.f : (float)(g * rs * s);
         if (training) {
             ca[c] = (float)(g * rs);
             cb[c] = (float)(-g * rs * rs * q / count);
@@ -158,11 +160,11 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* part,
 
 extern "C" int mia_bn_finalize_bwd(const float* part, int P, int C, double count, const float* gamma,
                                    const float* mean, const float* rstd, int training, float* dgamma, float* dbeta,
-                                   float* ca, float* cb, float* cd, void* stream) {
+                                   float* ca, float* cb, float* cd, float* dconv_bias, void* stream) {
     MIA_CHECK_ARG(part && P > 0 && C > 0 && count > 0 && mean && rstd && ca && cb && cd,
                   "mia_bn_finalize_bwd: bad arguments");
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       part, P, C, count, gamma, mean, rstd, training, dgamma, dbeta, ca, cb, cd);
+                       part, P, C, count, gamma, mean, rstd, training, dgamma, dbeta, ca, cb, cd, dconv_bias);
     MIA_CHECK_LAUNCH("mia_bn_finalize_bwd");
     return 0;
 }

@@ -159,10 +159,10 @@ def bn_finalize_fwd(part, count, bn: BNState, conv_bias=None):
 
 def bn_finalize_bwd(part, count, gamma, stats, training):
     C = gamma.shape[0]
-    coef = torch.empty((5, C), dtype=torch.float32, device=gamma.device)  # dgamma, dbeta, ca, cb, cd
+    coef = torch.empty((6, C), dtype=torch.float32, device=gamma.device)  # dgamma, dbeta, ca, cb, cd, dconv_bias
     lib().mia_bn_finalize_bwd(_p(part), part.shape[0], C, float(count), _p(gamma), _p(stats[2]), _p(stats[3]),
                               1 if training else 0, _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _p(coef[4]),
-                              _stream())
+                              _p(coef[5]), _stream())
     return coef
 
 

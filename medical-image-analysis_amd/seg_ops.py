@@ -79,7 +79,6 @@ class DecoderBlockFn(torch.autograd.Function):
         c2 = ops.bn_finalize_bwd(part, M, g2, st2, training)
         dy2 = ops.affine2(g, c2[2], c2[4], y=y2, b=c2[3], out=g)
         dw2 = ops.gemm_tn(dy2, col2)
-        db2 = colsum(dy2)
         dcol2, _ = ops.gemm_nt(dy2, ctx.w2mT)
         ga = col2im3x3(dcol2, (B, H, W, Co)).view(M, Co)
         # Dropout2d mask, ReLU and bn1 backward
@@ -87,12 +86,12 @@ class DecoderBlockFn(torch.autograd.Function):
         c1 = ops.bn_finalize_bwd(part, M, g1, st1, training)
         dy1 = ops.affine2(ga, c1[2], c1[4], y=y1, b=c1[3], out=ga)
         dw1 = ops.gemm_tn(dy1, col1)
-        db1 = colsum(dy1)
         dx = None
         if ctx.needs_input_grad[0]:
             dcol1, _ = ops.gemm_nt(dy1, ctx.w1mT)
             dx = col2im3x3(dcol1, (B, H, W, Cin))
-        return (dx, _weight_grad(dw1, w1), db1, c1[0], c1[1], _weight_grad(dw2, w2), db2, c2[0], c2[1], None)
+        # conv-bias gradients (column sums of dy1 / dy2) come out of the BatchNorm backward finalize in closed form
+        return (dx, _weight_grad(dw1, w1), c1[5], c1[0], c1[1], _weight_grad(dw2, w2), c2[5], c2[0], c2[1], None)
 
 
 class UpsampleConcatFn(torch.autograd.Function):

@@ -295,3 +295,22 @@ def test_cbam_large_map_matches_oracle(c, h, w, train):
     pr = dict(ref.named_parameters())
     for k, p in mine.named_parameters():
         assert rel(p.grad, pr[k].grad) < 1e-3, k
+
+
+def test_decoder_block_eval_mode_gradients_match_oracle():
+    """Frozen BatchNorm (eval mode, e.g. fine-tuning with the decoder's statistics fixed): here the conv biases DO
+    receive a gradient; every parameter and the input gradient are checked against the oracle block."""
+    from oracle import seg_ref as S
+    ref = load_seeded(S.DecoderBlock(24, 16, dropout=0.0), 51).eval()
+    mine = load_seeded(DecoderBlock(24, 16, dropout=0.0), 51).cuda().eval()
+    x = randn(52, 2, 24, 6, 7)
+    xr, xm = x.clone().requires_grad_(True), nhwc(x).cuda().requires_grad_(True)
+    out_r, out_m = ref(xr), mine(xm)
+    assert rel(out_m.permute(0, 3, 1, 2), out_r) < 1e-4
+    g = randn(53, *out_r.shape)
+    out_r.backward(g)
+    out_m.backward(nhwc(g).cuda())
+    assert rel(xm.grad.permute(0, 3, 1, 2), xr.grad) < 1e-3
+    pr = dict(ref.named_parameters())
+    for k, p in mine.named_parameters():
+        assert rel(p.grad, pr[k].grad) < 1e-3, k
