@@ -238,6 +238,16 @@ int mia_seg_loss_fwd(const float* logits, const long long* target, int B, int HW
 int mia_seg_loss_bwd(const float* logits, const long long* target, int B, int HW, int n, const float* class_weights,
                      const float* coef, const float* upstream, float* dlogits, void* stream);
 
+/* ---- evaluation counters (MetricsCalculator.update, src/metric.py:29-43: argmax + Python lists + scikit-learn
+ *      in the reference) -----------------------------------------------------------------------------------------
+ * conf[t*n + argmax_k logits] += 1 per sample/pixel (uint64 [n][n], caller zero-fills at reset), first maximum on
+ * ties; logits element (image b, class k, position p) at b*stride_image + k*stride_class + p*stride_pos (fp32);
+ * target [images*positions] int64, values outside [0,n) skipped. loss/loss_acc (nullable): loss_acc[0] += loss[0]
+ * (the running loss of train.py:355, kept on the device: no .item() per step). n <= 64. */
+int mia_confusion_update(const float* logits, long long stride_image, long long stride_class, long long stride_pos,
+                         const long long* target, long long images, long long positions, int n,
+                         unsigned long long* conf, const float* loss, double* loss_acc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,14 @@ MAX_PART = 512   # persistent workgroups (= BatchNorm partial rows) per launch: 
 
 
 def _p(t: Optional[torch.Tensor]):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    """Device pointer of a tensor for the C ABI. Every pointer handed to a kernel goes through here, so a host
+    tensor can never reach the GPU as an address (that would be a memory fault, not an exception)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("mia_amd kernels need tensors on an MI355X device; there is no CPU path "
+                           f"(got a {t.device} tensor of shape {tuple(t.shape)})")
+    return ctypes.c_void_p(t.data_ptr())
 
 
 def _stream():

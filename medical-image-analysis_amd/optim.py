@@ -44,7 +44,8 @@ class AdamW(torch.optim.Optimizer):
             if not ps:
                 continue
             for p in ps:
-                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or p.grad.is_sparse:
+                if (not p.is_cuda or not p.grad.is_cuda or p.dtype != torch.float32 or p.grad.dtype != torch.float32
+                        or not p.is_contiguous() or p.grad.is_sparse):
                     raise RuntimeError("mia_amd.optim.AdamW needs contiguous fp32 parameters on an MI355X device")
                 if not p.grad.is_contiguous():
                     p.grad = p.grad.contiguous()

@@ -80,15 +80,23 @@ class FoundationModel(nn.Module):
         self.backbone.compute_dtype = dtype if isinstance(dtype, torch.dtype) else _DTYPES[dtype]
         return self
 
+    def _check_device(self, x):
+        p = next(self.parameters())
+        if not x.is_cuda or not p.is_cuda:
+            raise RuntimeError("mia_amd kernels need the model and its input on an MI355X device; there is no CPU "
+                               f"path (input on {x.device}, parameters on {p.device})")
+
     def forward(self, x: torch.Tensor, task: str, dataset_name: str):
         if task == "classification":
             if dataset_name not in self.classification_layers:
                 raise ValueError(f"Classification head for {dataset_name} not found")
+            self._check_device(x)
             feats = self.backbone.forward_nhwc(x)
             return self.classification_layers[dataset_name](feats[-1])
         elif task == "segmentation":
             if dataset_name not in self.segmentation_layers:
                 raise ValueError(f"Segmentation head for {dataset_name} not found")
+            self._check_device(x)
             feats = self.backbone.forward_nhwc(x)
             return self.segmentation_layers[dataset_name](feats, x.shape[-2:])
         else:

@@ -155,5 +155,12 @@ def test_forward_errors_before_touching_the_device():
     assert "cbam_modules.4.SpatialGate.spatial.bn.running_var" in keys
     plain = FoundationModel(backbone="efficientnet_b3", pretrained=False, segmentation_heads={"s": 2}, use_attention=False)
     assert type(plain.segmentation_layers["s"]).__name__ == "UNetDecoder"
-    with pytest.raises(RuntimeError):      # no device, no fallback
+    # host tensors are refused before anything is launched (a host address inside a kernel would fault the GPU)
+    with pytest.raises(RuntimeError, match="no CPU path"):
         seg(x, "segmentation", "s")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(x, "classification", "a")
+    from mia_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops._p(torch.zeros(4))
+    assert ops._p(None) is None
