@@ -63,6 +63,86 @@ __global__ __launch_bounds__(256) void resize_normalize_kernel(const uint8_t* sr
     }
 }
 
+// The same arithmetic, tiled: one workgroup produces RZ_ROWS output rows of one image. The x and y coefficient
+// tables are computed once per workgroup, the source rows the tile needs are staged in LDS with 16-byte loads, and
+// every thread then produces four consecutive output pixels per channel (16-byte stores). Global memory sees only
+// streaming vector accesses; the twelve byte-sized taps per pixel are LDS reads.
+#define RZ_ROWS 20
+__global__ __launch_bounds__(256) void resize_normalize_tile_kernel(const uint8_t* src, int h, int w, int ch, float* dst,
+                                                                    int oh, int ow, float m0, float m1, float m2, float r0,
+                                                                    float r1, float r2, int mode) {
+    extern __shared__ __align__(16) uint8_t rz_lds[];
+    int4* cxs = reinterpret_cast<int4*>(rz_lds);   // per output column: byte offset of tap 0, of tap 1, weights
+    int4* cys = cxs + ow;                          // per output row of the tile: source rows, weights
+    uint8_t* rows = reinterpret_cast<uint8_t*>(cys + RZ_ROWS);
+    const int tid = threadIdx.x, n = blockIdx.y, oy0 = blockIdx.x * RZ_ROWS;
+    const int nr = (oh - oy0) < RZ_ROWS ? (oh - oy0) : RZ_ROWS;
+    for (int i = tid; i < ow; i += 256) {
+        const LinCoef c = lin_coef(i, w, ow);
+        cxs[i] = make_int4(c.s0 * ch, c.s1 * ch, c.w0, c.w1);
+    }
+    for (int i = tid; i < nr; i += 256) {
+        const LinCoef c = lin_coef(oy0 + i, h, oh);
+        cys[i] = make_int4(c.s0, c.s1, c.w0, c.w1);
+    }
+    __syncthreads();
+    const int y_first = cys[0].x, y_last = cys[nr - 1].y;
+    const size_t row_bytes = (size_t)w * ch;
+    const size_t total = (size_t)(y_last - y_first + 1) * row_bytes;
+    const uint8_t* sbase = src + ((size_t)n * h + y_first) * row_bytes;
+    if ((reinterpret_cast<uintptr_t>(sbase) & 15) == 0) {
+        const size_t vec_end = total & ~(size_t)15;
+        for (size_t i = (size_t)tid * 16; i < vec_end; i += 256 * 16)
+            *reinterpret_cast<uint4*>(rows + i) = *reinterpret_cast<const uint4*>(sbase + i);
+        for (size_t i = vec_end + tid; i < total; i += 256) rows[i] = sbase[i];
+    } else {
+        for (size_t i = tid; i < total; i += 256) rows[i] = sbase[i];
+    }
+    __syncthreads();
+    const float mm[3] = {m0, m1, m2}, rr[3] = {r0, r1, r2};
+    const int quads = (ow + 3) >> 2;
+    const bool vec_out = (ow & 3) == 0;
+    for (int item = tid; item < nr * quads; item += 256) {
+        const int r = item / quads, ox = (item % quads) * 4, oy = oy0 + r;
+        const int4 cy = cys[r];
+        const uint8_t* p0 = rows + (size_t)(cy.x - y_first) * row_bytes;
+        const uint8_t* p1 = rows + (size_t)(cy.y - y_first) * row_bytes;
+        float o[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int4 cx = cxs[(ox + j) < ow ? (ox + j) : (ow - 1)];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int cs = ch == 3 ? c : 0;
+                const int S0 = (int)p0[cx.x + cs] * cx.z + (int)p0[cx.y + cs] * cx.w;
+                const int S1 = (int)p1[cx.x + cs] * cx.z + (int)p1[cx.y + cs] * cx.w;
+                int v = ((cy.z * (S0 >> 4)) >> 16) + ((cy.w * (S1 >> 4)) >> 16);
+                v = (v + 2) >> 2;
+                v = v < 0 ? 0 : (v > 255 ? 255 : v);
+                float f;
+                if (mode == 0) {
+                    f = (float)v - mm[c];
+                    f = f * rr[c];
+                } else {
+                    f = (float)v / 255.0f;
+                }
+                o[c][j] = f;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float* d = dst + (((size_t)n * 3 + c) * oh + oy) * ow + ox;
+            if (vec_out) {
+                *reinterpret_cast<float4*>(d) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ox + j < ow) d[j] = o[c][j];
+            }
+        }
+    }
+}
+
 // mode 0: (x - 255*mean) * (1/(255*std));  mode 1: x / 255
 extern "C" int mia_resize_normalize_u8(const uint8_t* src, int N, int h, int w, int ch, float* dst, int oh, int ow,
                                        const float* mean3, const float* std3, int mode, void* stream) {
@@ -78,6 +158,18 @@ extern "C" int mia_resize_normalize_u8(const uint8_t* src, int N, int h, int w, 
             m[i] = mv;
             r[i] = rv;
         }
+    }
+    // tiled kernel when the tile's source rows fit in LDS: at most (RZ_ROWS-1)*h/oh + 3 rows (two taps per output
+    // row, monotone in the row index), one more for slack
+    const long long src_rows = ((long long)(RZ_ROWS - 1) * h + oh - 1) / oh + 4;
+    const long long lds = (long long)ow * 16 + RZ_ROWS * 16 + src_rows * (long long)w * ch + 16;
+    if (lds <= 64 * 1024 && N <= 65535 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+        dim3 grid((unsigned)((oh + RZ_ROWS - 1) / RZ_ROWS), (unsigned)N);
+        hipLaunchKernelGGL(resize_normalize_tile_kernel, grid, dim3(256), (size_t)lds,
+                           reinterpret_cast<hipStream_t>(stream), src, h, w, ch, dst, oh, ow, m[0], m[1], m[2], r[0], r[1],
+                           r[2], mode);
+        MIA_CHECK_LAUNCH("mia_resize_normalize_u8");
+        return 0;
     }
     const long long total = (long long)N * oh * ow;
     long long blocks = (total + 255) / 256;

@@ -22,7 +22,8 @@ def phantom(n, h, w, seed):
 
 @pytest.mark.parametrize("shape,out", [((4, 256, 256, 3), (300, 300)), ((3, 128, 128, 3), (64, 64)),
                                        ((2, 97, 131, 3), (300, 300)), ((2, 300, 300, 3), (300, 300)),
-                                       ((1, 1, 1, 3), (5, 7)), ((2, 512, 384, 3), (224, 224))])
+                                       ((1, 1, 1, 3), (5, 7)), ((2, 512, 384, 3), (224, 224)),
+                                       ((1, 1200, 1000, 3), (300, 300)), ((5, 256, 256, 3), (301, 299))])
 @pytest.mark.parametrize("normalize", [True, False])
 def test_resize_normalize_bit_exact(shape, out, normalize):
     rng = np.random.default_rng(3)
