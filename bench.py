@@ -79,6 +79,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    ndev = torch.cuda.device_count()
+    if world > ndev:
+        raise SystemExit(f"{world} ranks need {world} GPUs (one process per GPU over RCCL), this node has {ndev}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -146,6 +149,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_v = float(loss.item())
+    in_sync = None
+    if world > 1:
+        # replicas started identical and applied identical averaged gradients: their parameters must still agree
+        cs = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool((lo == hi).item())
 
     if rank == 0:
         ips = world * args.batch * args.steps / dt
@@ -177,6 +188,8 @@ def main():
                          "algorithmic_bytes_per_launch": int(nbytes / max(launches, 1))},
             "final_loss": round(loss_v, 4),
         }
+        if in_sync is not None:
+            out["replicas_in_sync"] = in_sync
         if args.kernel_table:
             tot = sum(v[1] for v in table.values())
             for fam, (n, fms, fb) in sorted(table.items(), key=lambda kv: -kv[1][1]):
