@@ -248,6 +248,20 @@ int mia_confusion_update(const float* logits, long long stride_image, long long 
                          const long long* target, long long images, long long positions, int n,
                          unsigned long long* conf, const float* loss, double* loss_acc, void* stream);
 
+/* ---- training-time augmentation (get_transforms(augment=True), src/dataset.py:229-239: A.Resize, HorizontalFlip,
+ *      VerticalFlip, Rotate(limit=15), RandomBrightnessContrast(0.2, 0.2), GaussianBlur(3), Normalize, ToTensorV2;
+ *      albumentations/OpenCV on DataLoader workers in the reference) ------------------------------------------------
+ * 8-bit bilinear resize to HWC x 3 (gray replicated): the uint8 stage the later transforms operate on. */
+int mia_resize_u8(const uint8_t* src, int N, int h, int w, int ch, uint8_t* dst, int oh, int ow, void* stream);
+/* src u8 [N,H,W,3] (resized) -> dst f32 [N,3,H,W] normalised. params: 9 doubles per image on the device:
+ * {hflip, vflip, rotate?, cos(angle), sin(angle), brightness/contrast?, alpha, beta*255, blur?}. Rotation about
+ * (W/2-0.5, H/2-0.5), bilinear with 1/32-pixel coordinates, reflect-101 border; brightness/contrast v*alpha+beta
+ * clipped and truncated to 8 bits; blur = [1 2 1]x[1 2 1]/16 with rounding, reflect-101. mean3/std3: host arrays. */
+int mia_augment_normalize_u8(const uint8_t* src, int N, int H, int W, const double* params, float* dst,
+                             const float* mean3, const float* std3, void* stream);
+/* the geometric part for label masks (dataset.py:208-213): flips + nearest-neighbour rotation; u8 [N,H,W] -> int64. */
+int mia_augment_mask_u8(const uint8_t* src, int N, int H, int W, const double* params, long long* dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

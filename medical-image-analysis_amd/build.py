@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmia_hip.so")
-SOURCES = ["runtime.hip", "gemm.hip", "dwconv.hip", "pointwise.hip", "head.hip", "preprocess.hip", "optim.hip", "seg.hip", "metrics.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "dwconv.hip", "pointwise.hip", "head.hip", "preprocess.hip", "optim.hip", "seg.hip", "metrics.hip", "augment.hip"]
 
 
 def _stale() -> bool:

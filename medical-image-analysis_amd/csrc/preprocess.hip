@@ -181,6 +181,41 @@ extern "C" int mia_resize_normalize_u8(const uint8_t* src, int N, int h, int w, 
     return 0;
 }
 
+// 8-bit result of the same resize, HWC with 3 channels (gray replicated): the input of the augmentation kernels
+__global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t* src, int N, int h, int w, int ch, uint8_t* dst,
+                                                        int oh, int ow) {
+    const long long total = (long long)N * oh * ow;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ox = (int)(i % ow), oy = (int)((i / ow) % oh), n = (int)(i / ((long long)ow * oh));
+        const LinCoef cx = lin_coef(ox, w, ow), cy = lin_coef(oy, h, oh);
+        const uint8_t* img = src + (size_t)n * h * w * ch;
+        const uint8_t* p00 = img + ((size_t)cy.s0 * w + cx.s0) * ch;
+        const uint8_t* p01 = img + ((size_t)cy.s0 * w + cx.s1) * ch;
+        const uint8_t* p10 = img + ((size_t)cy.s1 * w + cx.s0) * ch;
+        const uint8_t* p11 = img + ((size_t)cy.s1 * w + cx.s1) * ch;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int cs = ch == 3 ? c : 0;
+            const int S0 = (int)p00[cs] * cx.w0 + (int)p01[cs] * cx.w1;
+            const int S1 = (int)p10[cs] * cx.w0 + (int)p11[cs] * cx.w1;
+            int v = ((cy.w0 * (S0 >> 4)) >> 16) + ((cy.w1 * (S1 >> 4)) >> 16);
+            v = (v + 2) >> 2;
+            dst[(size_t)i * 3 + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}
+
+extern "C" int mia_resize_u8(const uint8_t* src, int N, int h, int w, int ch, uint8_t* dst, int oh, int ow, void* stream) {
+    MIA_CHECK_ARG(src && dst && N > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "mia_resize_u8: bad arguments");
+    MIA_CHECK_ARG(ch == 1 || ch == 3, "mia_resize_u8: channels must be 1 or 3, got %d", ch);
+    long long blocks = ((long long)N * oh * ow + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(resize_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src,
+                       N, h, w, ch, dst, oh, ow);
+    MIA_CHECK_LAUNCH("mia_resize_u8");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // zero-intensity slice filter
 // ------------------------------------------------------------------------------------------------

@@ -81,3 +81,19 @@ for batch in (128, 512, 2048):
                       "gpu_us": round(t * 1e6, 1), "images_per_s": round(batch / t), "GB_per_s": round(nbytes / t / 1e9, 1),
                       "frac_hbm": round(nbytes / t / 1e9 / HBM_PEAK, 3), "cpu_numpy_images_per_s": round(1 / t_c, 1),
                       "cpu_cores": 1}), flush=True)
+
+from mia_amd.augment import TrainTransform
+from oracle import augment_ref as A
+for batch in (128, 512):
+    img_h = rng.integers(0, 256, (batch, 256, 256, 3), dtype=np.uint8)
+    img = torch.from_numpy(img_h).to(dev)
+    tf = TrainTransform((300, 300), seed=0)
+    plist = tf.sample(batch)
+    out = tf(img, params=plist)
+    assert np.array_equal(out[0].cpu().numpy(), A.train_transform(img_h[0], 300, 300, plist[0]))
+    t = gpu_time(lambda: tf(img, params=plist), iters=10)
+    t_c = cpu_time(lambda: A.train_transform(img_h[0], 300, 300, plist[0]))
+    print(json.dumps({"case": "train_transform (resize + flips + rotate + brightness/contrast + blur + normalise)",
+                      "images": batch, "gpu_us": round(t * 1e6, 1), "images_per_s": round(batch / t),
+                      "note": "includes the host-side parameter table upload", "cpu_numpy_images_per_s": round(1 / t_c, 1),
+                      "cpu_cores": 1}), flush=True)
