@@ -148,8 +148,9 @@ int mia_cbam_bwd(int dtype, const void* dx2, const void* x, int B, int H, int W,
  * uses a counter-based mask from `seed` that the backward regenerates. HW <= 256, HD in {8,16,32,48,64}. */
 int mia_attention_fwd(int dtype, const void* qkv, int B, int HW, int C, int heads, float pdrop,
                       unsigned long long seed, float* P, void* out, void* stream);
-int mia_attention_bwd(int dtype, const void* qkv, const float* P, const void* dout, int B, int HW, int C, int heads,
-                      float pdrop, unsigned long long seed, void* dqkv, void* stream);
+/* out: the forward's output (the row sums of P o dP are formed as dout . out). */
+int mia_attention_bwd(int dtype, const void* qkv, const float* P, const void* dout, const void* out, int B, int HW,
+                      int C, int heads, float pdrop, unsigned long long seed, void* dqkv, void* stream);
 
 /* ---- classifier front end: AdaptiveAvgPool2d(1) -> Flatten -> [LayerNorm] -> Dropout (model.py:134-137, :309-311)
  * in_part [B][S][C]: per-image channel sums over H*W (mia_img_colsum). gamma/beta NULL = no LayerNorm. */

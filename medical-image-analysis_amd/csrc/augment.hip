@@ -11,10 +11,14 @@
 // per-image parameters, 9 doubles: hflip, vflip, rotate?, cos, sin, brightness/contrast?, alpha, beta*255, blur?
 #define AUG_NP 9
 
+// reflect-101 index (... 2 1 | 0 1 2 .. n-1 | n-2 n-3 ...) in closed form: no loop, any int in (garbage parameters
+// cannot hang a wave)
 __device__ __forceinline__ int reflect101(int i, int n) {
     if (n == 1) return 0;
-    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
-    return i;
+    const int period = 2 * (n - 1);
+    int m = i % period;
+    if (m < 0) m += period;
+    return m < n ? m : period - m;
 }
 
 struct AugImg {

@@ -575,15 +575,19 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const T* qkv, int HW
     }
 }
 
-// backward: dqkv from dO, P and qkv. Phase A (thread = query row): D_r and dQ; phase B (thread = key row): dK, dV.
+// backward: dqkv from dO, O, P and qkv. Phase A (thread = query row): D_r = dO_r . O_r (the row sum of P o dP, by
+// O = P_dropped V) and dQ, with P staged through LDS in key chunks so its global reads are row segments; phase B
+// (thread = key row): dK, dV.
+#define ATT_JC 25
 template <typename T, int HD>
-__global__ __launch_bounds__(256) void attention_bwd_kernel(const T* qkv, const float* P, const T* dout, int HW, int C,
-                                                            int heads, float scale, float pdrop,
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const T* qkv, const float* P, const T* dout, const T* out,
+                                                            int HW, int C, int heads, float scale, float pdrop,
                                                             unsigned long long seed, T* dqkv) {
     extern __shared__ float sm[];
     float* As = sm;             // phase A: K ; phase B: Q
     float* Bs = sm + HW * HD;   // phase A: V ; phase B: dO
     float* Dr = sm + 2 * HW * HD;  // [HW]
+    float* Pl = Dr + HW;           // [ATT_JC][HW] chunk of P, key-major
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
     const size_t row0 = (size_t)b * HW;
     const int ld = 3 * C;
@@ -593,33 +597,39 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* qkv, const 
         As[i] = to_f32<T>(qkv[(row0 + r) * ld + C + h * HD + d]);
         Bs[i] = to_f32<T>(qkv[(row0 + r) * ld + 2 * C + h * HD + d]);
     }
-    __syncthreads();
-    for (int r = threadIdx.x; r < HW; r += 256) {
-        float g[HD];
+    // rows are handled in passes of 256 (HW <= 256: one pass); every thread joins the chunk loads and barriers
+    const int r = threadIdx.x;
+    const bool live = r < HW;
+    float g[HD], dq[HD];
+    float D = 0.f;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) g[d] = to_f32<T>(dout[(row0 + r) * C + h * HD + d]);
-        const float* prow = P + (pbase + r) * HW;
-        float D = 0.f;
-        for (int j = 0; j < HW; ++j) {
-            float dp = 0.f;
-#pragma unroll
-            for (int d = 0; d < HD; ++d) dp += g[d] * Bs[j * HD + d];
-            dp *= drop_scale(seed, (pbase + r) * HW + j, pdrop);
-            D += prow[j] * dp;
+    for (int d = 0; d < HD; ++d) {
+        g[d] = live ? to_f32<T>(dout[(row0 + r) * C + h * HD + d]) : 0.f;
+        dq[d] = 0.f;
+        if (live) D += g[d] * to_f32<T>(out[(row0 + r) * C + h * HD + d]);
+    }
+    if (live) Dr[r] = D;
+    for (int j0 = 0; j0 < HW; j0 += ATT_JC) {
+        const int jc = (HW - j0) < ATT_JC ? (HW - j0) : ATT_JC;
+        __syncthreads();   // previous chunk consumed (first pass: K, V staged)
+        for (int i = threadIdx.x; i < HW * jc; i += 256) {
+            const int rr = i / jc, jj = i % jc;
+            Pl[jj * HW + rr] = P[(pbase + rr) * HW + j0 + jj];
         }
-        Dr[r] = D;
-        float dq[HD];
+        __syncthreads();
+        if (live)
+            for (int jj = 0; jj < jc; ++jj) {
+                const int j = j0 + jj;
+                float dp = 0.f;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) dq[d] = 0.f;
-        for (int j = 0; j < HW; ++j) {
-            float dp = 0.f;
+                for (int d = 0; d < HD; ++d) dp += g[d] * Bs[j * HD + d];
+                dp *= drop_scale(seed, (pbase + r) * HW + j, pdrop);
+                const float ds = Pl[jj * HW + r] * (dp - D) * scale;
 #pragma unroll
-            for (int d = 0; d < HD; ++d) dp += g[d] * Bs[j * HD + d];
-            dp *= drop_scale(seed, (pbase + r) * HW + j, pdrop);
-            const float ds = prow[j] * (dp - D) * scale;
-#pragma unroll
-            for (int d = 0; d < HD; ++d) dq[d] += ds * As[j * HD + d];
-        }
+                for (int d = 0; d < HD; ++d) dq[d] += ds * As[j * HD + d];
+            }
+    }
+    if (live) {
 #pragma unroll
         for (int d = 0; d < HD; ++d) dqkv[(row0 + r) * ld + h * HD + d] = from_f32<T>(dq[d]);
     }
@@ -983,11 +993,11 @@ extern "C" int mia_cbam_bwd(int dtype, const void* dx2, const void* x, int B, in
 }
 
 template <typename T>
-static int launch_attention(bool fwd, const void* qkv, const float* P, const void* dout, int B, int HW, int C, int heads,
+static int launch_attention(bool fwd, const void* qkv, const float* P, const void* dout, const void* o, int B, int HW, int C, int heads,
                             float pdrop, unsigned long long seed, float* Pout, void* out, hipStream_t s) {
     const int HD = C / heads;
     const float scale = 1.0f / sqrtf((float)HD);
-    const size_t lds = ((size_t)2 * HW * HD + (fwd ? 0 : HW)) * 4;
+    const size_t lds = ((size_t)2 * HW * HD + (fwd ? 0 : HW + (size_t)ATT_JC * HW)) * 4;
     dim3 grid(B * heads);
 #define MIA_ATT(HD_)                                                                                                  \
     do {                                                                                                              \
@@ -998,7 +1008,7 @@ static int launch_attention(bool fwd, const void* qkv, const float* P, const voi
         } else {                                                                                                      \
             auto k = attention_bwd_kernel<T, HD_>;                                                                    \
             if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const T*)qkv, P, (const T*)dout, HW, C, heads, scale, pdrop, seed, (T*)out); \
+            hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const T*)qkv, P, (const T*)dout, (const T*)o, HW, C, heads, scale, pdrop, seed, (T*)out); \
         }                                                                                                             \
     } while (0)
     if (HD == 48) MIA_ATT(48);
@@ -1025,20 +1035,21 @@ extern "C" int mia_attention_fwd(int dtype, const void* qkv, int B, int HW, int 
     if (attention_checks("mia_attention_fwd", B, HW, C, heads)) return -1;
     MIA_CHECK_ARG(qkv && P && out, "mia_attention_fwd: null");
     int rc = dtype == MIA_BF16
-                 ? launch_attention<bf16_t>(true, qkv, nullptr, nullptr, B, HW, C, heads, pdrop, seed, P, out, MIA_STREAM)
-                 : launch_attention<float>(true, qkv, nullptr, nullptr, B, HW, C, heads, pdrop, seed, P, out, MIA_STREAM);
+                 ? launch_attention<bf16_t>(true, qkv, nullptr, nullptr, nullptr, B, HW, C, heads, pdrop, seed, P, out, MIA_STREAM)
+                 : launch_attention<float>(true, qkv, nullptr, nullptr, nullptr, B, HW, C, heads, pdrop, seed, P, out, MIA_STREAM);
     MIA_CHECK_ARG(rc == 0, "mia_attention_fwd: dispatch failed");
     MIA_CHECK_LAUNCH("mia_attention_fwd");
     return 0;
 }
 
-extern "C" int mia_attention_bwd(int dtype, const void* qkv, const float* P, const void* dout, int B, int HW, int C,
-                                 int heads, float pdrop, unsigned long long seed, void* dqkv, void* stream) {
+extern "C" int mia_attention_bwd(int dtype, const void* qkv, const float* P, const void* dout, const void* out, int B,
+                                 int HW, int C, int heads, float pdrop, unsigned long long seed, void* dqkv,
+                                 void* stream) {
     if (attention_checks("mia_attention_bwd", B, HW, C, heads)) return -1;
-    MIA_CHECK_ARG(qkv && P && dout && dqkv, "mia_attention_bwd: null");
+    MIA_CHECK_ARG(qkv && P && dout && out && dqkv, "mia_attention_bwd: null");
     int rc = dtype == MIA_BF16
-                 ? launch_attention<bf16_t>(false, qkv, P, dout, B, HW, C, heads, pdrop, seed, nullptr, dqkv, MIA_STREAM)
-                 : launch_attention<float>(false, qkv, P, dout, B, HW, C, heads, pdrop, seed, nullptr, dqkv, MIA_STREAM);
+                 ? launch_attention<bf16_t>(false, qkv, P, dout, out, B, HW, C, heads, pdrop, seed, nullptr, dqkv, MIA_STREAM)
+                 : launch_attention<float>(false, qkv, P, dout, out, B, HW, C, heads, pdrop, seed, nullptr, dqkv, MIA_STREAM);
     MIA_CHECK_ARG(rc == 0, "mia_attention_bwd: dispatch failed");
     MIA_CHECK_LAUNCH("mia_attention_bwd");
     return 0;

@@ -135,16 +135,16 @@ class AttentionFn(torch.autograd.Function):
         out = torch.empty((B * HW, C), dtype=qkv.dtype, device=qkv.device)
         lib().mia_attention_fwd(_DT[qkv.dtype], _p(qkv), B, HW, C, heads, float(pdrop), seed, _p(P), _p(out), _stream())
         ctx.meta = (B, HW, C, heads, float(pdrop), seed)
-        ctx.save_for_backward(qkv, P)
+        ctx.save_for_backward(qkv, P, out)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, P = ctx.saved_tensors
+        qkv, P, out = ctx.saved_tensors
         B, HW, C, heads, pdrop, seed = ctx.meta
         dqkv = torch.empty_like(qkv)
-        lib().mia_attention_bwd(_DT[qkv.dtype], _p(qkv), _p(P), _p(dout.contiguous()), B, HW, C, heads, pdrop, seed,
-                                _p(dqkv), _stream())
+        lib().mia_attention_bwd(_DT[qkv.dtype], _p(qkv), _p(P), _p(dout.contiguous()), _p(out), B, HW, C, heads, pdrop,
+                                seed, _p(dqkv), _stream())
         return dqkv, None, None, None, None, None, None
 
 
