@@ -608,7 +608,10 @@ struct GemmTNParams {
     int chunks_per_split;
 };
 
-template <typename T, bool PRO>
+// LAYOUT: how the four waves share the 128x128 tile. 0: 2x2 waves of 64x64. 1: the k extent of the whole product
+// is <= 64 (narrow activations: 24..40 input channels): 4x1 waves of 32(n) x 64(k), so every wave has work and the
+// accumulators halve. 2: the n extent is <= 64: 1x4 waves of 64(n) x 32(k).
+template <typename T, bool PRO, int LAYOUT>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
     using M_ = Mma<T>;
     using V_ = Vec16<T>;
@@ -617,7 +620,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
     constexpr int VEC = V_::N;
     constexpr int LD = BT + VEC;     // LDS row stride, elements
     constexpr int CH = BR * (BT / VEC) / 256;  // 16-byte chunks per thread and operand at full tile width
-    constexpr int MT = 4, NT = 4;    // 64x64 per wave
+    constexpr int WR = LAYOUT == 1 ? 4 : (LAYOUT == 2 ? 1 : 2), WC = 4 / WR;   // waves along n, along k
+    constexpr int WN = (LAYOUT == 2 ? 64 : 128) / WR, WK = (LAYOUT == 1 ? 64 : 128) / WC;   // wave tile
+    constexpr int MT = WN / 16, NT = WK / 16;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* Gs = reinterpret_cast<T*>(smem);  // [BR][LD]
@@ -627,16 +632,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
     const T* __restrict__ G = reinterpret_cast<const T*>(p.G);
     const T* __restrict__ X = reinterpret_cast<const T*>(p.X);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WC, wc = wave % WC;
     const int n0 = blockIdx.x * BT, k0 = blockIdx.y * BT;
     const int M = p.M, N = p.N, K = p.K;
     const bool has_pro = PRO && p.pscale != nullptr;
     const bool has_gate = PRO && p.gate != nullptr;
 
     // tiles of this wave that hold any valid output
-    const int nvalid = N - (n0 + wr * 64), kvalid = K - (k0 + wc * 64);
-    const int mt_cnt = nvalid <= 0 ? 0 : (nvalid >= 64 ? 4 : (nvalid + 15) / 16);
-    const int nt_cnt = kvalid <= 0 ? 0 : (kvalid >= 64 ? 4 : (kvalid + 15) / 16);
+    const int nvalid = N - (n0 + wr * WN), kvalid = K - (k0 + wc * WK);
+    const int mt_cnt = nvalid <= 0 ? 0 : (nvalid >= WN ? MT : (nvalid + 15) / 16);
+    const int nt_cnt = kvalid <= 0 ? 0 : (kvalid >= WK ? NT : (kvalid + 15) / 16);
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -748,10 +753,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
                 typename M_::Frag a[MT], b[NT];
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
-                    a[i] = M_::load_t(Gs + kk * M_::KSTEP * LD + wr * 64 + i * 16, LD, lane);
+                    a[i] = M_::load_t(Gs + kk * M_::KSTEP * LD + wr * WN + i * 16, LD, lane);
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    b[j] = M_::load_t(Xs + kk * M_::KSTEP * LD + wc * 64 + j * 16, LD, lane);
+                    b[j] = M_::load_t(Xs + kk * M_::KSTEP * LD + wc * WK + j * 16, LD, lane);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -767,10 +772,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             if (i < mt_cnt && j < nt_cnt) {
-                const int gk = k0 + wc * 64 + j * 16 + lcol;
+                const int gk = k0 + wc * WK + j * 16 + lcol;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int gn = n0 + wr * 64 + i * 16 + lrow + r;
+                    const int gn = n0 + wr * WN + i * 16 + lrow + r;
                     if (gn < N && gk < K) atomicAdd(p.O + (size_t)gn * p.ldo + gk, acc[i][j][r]);
                 }
             }
@@ -809,15 +814,27 @@ extern "C" int mia_gemm_tn(int dtype, const void* G, int ldg, const void* X, int
     dim3 grid(cdiv(N, 128), cdiv(K, 128), (unsigned)splits);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool pro = pscale || gate;
+    const int layout = K <= 64 ? 1 : (N <= 64 ? 2 : 0);
+#define MIA_TN_LAUNCH(T_, LDS_)                                                                              \
+    do {                                                                                                     \
+        if (pro) {                                                                                           \
+            if (layout == 1) hipLaunchKernelGGL((gemm_tn_kernel<T_, true, 1>), grid, dim3(256), LDS_, s, p);   \
+            else if (layout == 2) hipLaunchKernelGGL((gemm_tn_kernel<T_, true, 2>), grid, dim3(256), LDS_, s, p); \
+            else hipLaunchKernelGGL((gemm_tn_kernel<T_, true, 0>), grid, dim3(256), LDS_, s, p);               \
+        } else {                                                                                             \
+            if (layout == 1) hipLaunchKernelGGL((gemm_tn_kernel<T_, false, 1>), grid, dim3(256), LDS_, s, p);  \
+            else if (layout == 2) hipLaunchKernelGGL((gemm_tn_kernel<T_, false, 2>), grid, dim3(256), LDS_, s, p); \
+            else hipLaunchKernelGGL((gemm_tn_kernel<T_, false, 0>), grid, dim3(256), LDS_, s, p);              \
+        }                                                                                                    \
+    } while (0)
     if (dtype == MIA_BF16) {
         constexpr int LDS = 2 * 64 * (128 + 8) * 2 + 2 * 128 * 4;
-        if (pro) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, true>), grid, dim3(256), LDS, s, p);
-        else hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, false>), grid, dim3(256), LDS, s, p);
+        MIA_TN_LAUNCH(bf16_t, LDS);
     } else {
         constexpr int LDS = 2 * 32 * (128 + 4) * 4 + 2 * 128 * 4;
-        if (pro) hipLaunchKernelGGL((gemm_tn_kernel<float, true>), grid, dim3(256), LDS, s, p);
-        else hipLaunchKernelGGL((gemm_tn_kernel<float, false>), grid, dim3(256), LDS, s, p);
+        MIA_TN_LAUNCH(float, LDS);
     }
+#undef MIA_TN_LAUNCH
     MIA_CHECK_LAUNCH("mia_gemm_tn");
     return 0;
 }
