@@ -804,16 +804,20 @@ extern "C" int mia_gemm_tn(int dtype, const void* G, int ldg, const void* X, int
     const int BR = dtype == MIA_BF16 ? 64 : 32;
     const int tiles = cdiv(N, 128) * cdiv(K, 128);
     const long long chunks = ((long long)M + BR - 1) / BR;
-    // aim for ~512 blocks (two per CU; more splits cost more atomic traffic), at least 4 reduction chunks each
+    // aim for ~512 blocks (two per CU). Every split ends with one float atomic per output element, so short splits
+    // are dominated by that traffic: at least 16 reduction chunks per split for the plain variant (measured on the
+    // 1392x232 gradient at M = 12800: 23 splits 59 us, 12 splits 46 us), 4 for the prologue variant, whose chunks
+    // carry the activation work and prefer the parallelism
+    const bool pro = pscale || gate;
+    const int min_chunks = pro ? 4 : 16;
     long long splits = 512 / tiles;
     if (splits < 1) splits = 1;
-    if (splits > (chunks + 3) / 4) splits = (chunks + 3) / 4;
+    if (splits > (chunks + min_chunks - 1) / min_chunks) splits = (chunks + min_chunks - 1) / min_chunks;
     if (splits < 1) splits = 1;
     p.chunks_per_split = (int)((chunks + splits - 1) / splits);
     splits = (chunks + p.chunks_per_split - 1) / p.chunks_per_split;
     dim3 grid(cdiv(N, 128), cdiv(K, 128), (unsigned)splits);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const bool pro = pscale || gate;
     const int layout = K <= 64 ? 1 : (N <= 64 ? 2 : 0);
 #define MIA_TN_LAUNCH(T_, LDS_)                                                                              \
     do {                                                                                                     \
