@@ -274,11 +274,13 @@ def test_segmentation_step_matches_oracle_fp32(use_attention):
     assert worst[0] < 2e-3, worst
 
 
-@pytest.mark.parametrize("c,h,w", [(16, 48, 48), (32, 75, 75), (256, 19, 19), (64, 40, 33)])
+@pytest.mark.parametrize("c,h,w", [(16, 48, 48), (32, 75, 75), (256, 19, 19), (64, 40, 33), (16, 150, 150)])
 @pytest.mark.parametrize("train", [True, False])
 def test_cbam_large_map_matches_oracle(c, h, w, train):
     """Decoder-level CBAM shapes take the row-split reduction kernels; the oracle's CBAM (itself pinned to the
-    reference's by the small goldens) is the checker. ReLU-like inputs (many exact zeros and ties) included."""
+    reference's by the small goldens) is the checker. ReLU-like inputs (many exact zeros and ties) included. The
+    150x150 case (45,000 pixels in the batch) also takes the two-launch BatchNorm(1) backward and the chunked 7x7
+    weight gradient."""
     from oracle import effnet_b3 as O
     from mia_amd.heads import CBAM
     ref = load_seeded(O.CBAM(c), 81).train(train)
@@ -314,3 +316,25 @@ def test_decoder_block_eval_mode_gradients_match_oracle():
     pr = dict(ref.named_parameters())
     for k, p in mine.named_parameters():
         assert rel(p.grad, pr[k].grad) < 1e-3, k
+
+
+def test_segmentation_full_size_matches_oracle_fp32():
+    """300x300 input (the size of the headline configuration), batch 2, eval mode: whole segmentation forward against
+    the CPU oracle. Every decoder level runs at its real spatial size (10, 19, 38, 75, 150, then 300)."""
+    from oracle import effnet_b3 as O
+    from seeding import seeded_state_dict
+    from mia_amd.src.model import FoundationModel, load_model_weights_safely
+    ref = O.OracleFoundationModel({}, dropout=0.0, use_attention=True, segmentation_heads={"seg": 2}).eval()
+    sd = seeded_state_dict(ref, 6)
+    ref.load_state_dict(sd)
+    mine = FoundationModel(backbone="efficientnet_b3", pretrained=False, dropout=0.0, classification_heads={},
+                           segmentation_heads={"seg": 2}, use_attention=True)
+    load_model_weights_safely(mine, sd)
+    mine = mine.cuda().eval()
+    x = randn(201, 2, 3, 300, 300)
+    with torch.no_grad():
+        lr = ref(x, "segmentation", "seg")
+        lm = mine(x.cuda(), "segmentation", "seg")
+    assert lm.shape == (2, 2, 300, 300)
+    assert rel(lm, lr) < 1e-4
+    assert (lm.argmax(1).cpu() == lr.argmax(1)).float().mean().item() > 0.999
