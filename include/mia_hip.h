@@ -263,6 +263,22 @@ int mia_augment_normalize_u8(const uint8_t* src, int N, int H, int W, const doub
 /* the geometric part for label masks (dataset.py:208-213): flips + nearest-neighbour rotation; u8 [N,H,W] -> int64. */
 int mia_augment_mask_u8(const uint8_t* src, int N, int H, int W, const double* params, long long* dst, void* stream);
 
+/* ---- the other loss variants of src/loss.py: FocalLoss (:83-102) and class-weighted nn.CrossEntropyLoss (:143-147) on
+ *      class logits [B,n] or pixel logits [B,n,HW] (strides as in mia_confusion_update) ------------------------------
+ * plain: l_i = w[t_i]*ce_i, mean = sum l / sum w[t]; focal: l_i = alpha*(1-pt_i)^gamma*ce_i, mean = sum l / count.
+ * mean = 0 gives the sum. per_elem (nullable): l_i. partial: [partial_rows][2] scratch. out[0] = loss, out[1] = the
+ * factor the backward applies (kept for it). */
+int mia_ce_general_fwd(const float* logits, long long stride_image, long long stride_class, long long stride_pos,
+                       const long long* target, long long images, long long positions, int n,
+                       const float* class_weights, int focal, float alpha, float gamma, int mean, float* per_elem,
+                       float* partial, int partial_rows, float* out, void* stream);
+/* dlogits (same strides) = upstream * out[1] * d l_i/d logits; upstream: device scalar (upstream_per_elem = 0) or one
+ * value per element (reduction 'none'; pass out = NULL then). */
+int mia_ce_general_bwd(const float* logits, long long stride_image, long long stride_class, long long stride_pos,
+                       const long long* target, long long images, long long positions, int n,
+                       const float* class_weights, int focal, float alpha, float gamma, const float* out,
+                       const float* upstream, int upstream_per_elem, float* dlogits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

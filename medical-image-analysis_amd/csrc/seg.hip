@@ -566,3 +566,135 @@ extern "C" int mia_seg_loss_bwd(const float* logits, const long long* target, in
     MIA_CHECK_LAUNCH("mia_seg_loss_bwd");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// General softmax cross-entropy over strided fp32 logits (class logits [B,n] or pixel logits [B,n,HW]; element
+// (image b, class k, position p) at b*sb + k*sk + p*sp) with optional class weights and focal modulation:
+//   plain:  l_i = w[t_i] * ce_i,                     mean = sum l_i / sum w[t_i]
+//   focal:  l_i = alpha * (1 - pt_i)^gamma * ce_i,   pt_i = exp(-ce_i),   mean = sum l_i / count
+// Targets outside [0, n) are skipped. Any number of classes (the class loop recomputes instead of keeping arrays).
+// ------------------------------------------------------------------------------------------------
+struct CeElem {
+    float ce, pt, lse;
+    int t;
+};
+__device__ __forceinline__ CeElem ce_elem(const float* z, long long sk, int n, long long t) {
+    float m = z[0];
+    for (int k = 1; k < n; ++k) m = fmaxf(m, z[k * sk]);
+    float s = 0.f;
+    for (int k = 0; k < n; ++k) s += expf(z[k * sk] - m);
+    CeElem e;
+    e.lse = m + logf(s);
+    e.t = (t >= 0 && t < n) ? (int)t : -1;
+    e.ce = e.t >= 0 ? e.lse - z[e.t * sk] : 0.f;
+    e.pt = expf(-e.ce);
+    return e;
+}
+
+__global__ __launch_bounds__(256) void ce_general_fwd_kernel(const float* logits, long long sb, long long sk, long long sp,
+                                                             const long long* target, long long total, long long P, int n,
+                                                             const float* cw, int focal, float alpha, float gamma,
+                                                             float* per_elem, float* partial) {
+    __shared__ float red[2][4];
+    float num = 0.f, den = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const CeElem e = ce_elem(logits + (i / P) * sb + (i % P) * sp, sk, n, target[i]);
+        float l = 0.f;
+        if (e.t >= 0) {
+            if (focal) {
+                l = alpha * powf(fmaxf(1.f - e.pt, 0.f), gamma) * e.ce;
+                den += 1.f;
+            } else {
+                const float w = cw ? cw[e.t] : 1.f;
+                l = w * e.ce;
+                den += w;
+            }
+        }
+        num += l;
+        if (per_elem) per_elem[i] = l;
+    }
+    num = wave_sum(num);
+    den = wave_sum(den);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = num; red[1][threadIdx.x >> 6] = den; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x * 2 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        partial[blockIdx.x * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+// out[0] = loss, out[1] = the factor every element's gradient carries (1/denominator for the mean, 1 for the sum)
+__global__ __launch_bounds__(256) void ce_general_finalize_kernel(const float* partial, int parts, int mean, float* out) {
+    __shared__ double sh[2][256];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < parts; i += 256) { a += partial[i * 2]; b += partial[i * 2 + 1]; }
+    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double num = sh[0][0], den = sh[1][0];
+        out[0] = (float)(mean ? (den > 0.0 ? num / den : 0.0) : num);
+        out[1] = (float)(mean ? (den > 0.0 ? 1.0 / den : 0.0) : 1.0);
+    }
+}
+
+// dlogits (same strides as logits) = upstream * scale * d l_i / d z;  upstream: one scalar, or one value per element
+__global__ __launch_bounds__(256) void ce_general_bwd_kernel(const float* logits, long long sb, long long sk, long long sp,
+                                                             const long long* target, long long total, long long P, int n,
+                                                             const float* cw, int focal, float alpha, float gamma,
+                                                             const float* scale, const float* upstream, int upstream_per_elem,
+                                                             float* dlogits) {
+    const float sc = scale ? scale[1] : 1.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long off = (i / P) * sb + (i % P) * sp;
+        const CeElem e = ce_elem(logits + off, sk, n, target[i]);
+        float f = 0.f;
+        if (e.t >= 0) {
+            if (focal) {
+                const float q = fmaxf(1.f - e.pt, 1e-12f);
+                f = alpha * (powf(q, gamma) + gamma * e.pt * powf(q, gamma - 1.f) * e.ce);
+            } else {
+                f = cw ? cw[e.t] : 1.f;
+            }
+        }
+        const float up = upstream ? upstream[upstream_per_elem ? i : 0] : 1.f;
+        f *= sc * up;
+        for (int k = 0; k < n; ++k) {
+            const float p = expf(logits[off + k * sk] - e.lse);
+            dlogits[off + k * sk] = f * (p - (k == e.t ? 1.f : 0.f));
+        }
+    }
+}
+
+extern "C" int mia_ce_general_fwd(const float* logits, long long stride_image, long long stride_class,
+                                  long long stride_pos, const long long* target, long long images, long long positions,
+                                  int n, const float* class_weights, int focal, float alpha, float gamma, int mean,
+                                  float* per_elem, float* partial, int partial_rows, float* out, void* stream) {
+    MIA_CHECK_ARG(logits && target && partial && out && images > 0 && positions > 0 && n > 0 && partial_rows > 0 &&
+                      partial_rows <= 4096,
+                  "mia_ce_general_fwd: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(ce_general_fwd_kernel, dim3(partial_rows), dim3(256), 0, s, logits, stride_image, stride_class,
+                       stride_pos, target, images * positions, positions, n, class_weights, focal, alpha, gamma, per_elem,
+                       partial);
+    hipLaunchKernelGGL(ce_general_finalize_kernel, dim3(1), dim3(256), 0, s, partial, partial_rows, mean, out);
+    MIA_CHECK_LAUNCH("mia_ce_general_fwd");
+    return 0;
+}
+
+extern "C" int mia_ce_general_bwd(const float* logits, long long stride_image, long long stride_class,
+                                  long long stride_pos, const long long* target, long long images, long long positions,
+                                  int n, const float* class_weights, int focal, float alpha, float gamma,
+                                  const float* out, const float* upstream, int upstream_per_elem, float* dlogits,
+                                  void* stream) {
+    MIA_CHECK_ARG(logits && target && dlogits && images > 0 && positions > 0 && n > 0, "mia_ce_general_bwd: bad arguments");
+    hipLaunchKernelGGL(ce_general_bwd_kernel, dim3(grid_for(images * positions, 4096)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), logits, stride_image, stride_class, stride_pos, target,
+                       images * positions, positions, n, class_weights, focal, alpha, gamma, out, upstream,
+                       upstream_per_elem, dlogits);
+    MIA_CHECK_LAUNCH("mia_ce_general_bwd");
+    return 0;
+}

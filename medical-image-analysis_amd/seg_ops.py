@@ -214,3 +214,44 @@ class SegLossFn(torch.autograd.Function):
 
 def seg_loss(logits, target, *, class_weights=None, iou=False, smooth=1e-5, ce_weight=0.5, overlap_weight=0.5):
     return SegLossFn.apply(logits, target, class_weights, iou, smooth, ce_weight, overlap_weight)
+
+
+class GeneralCEFn(torch.autograd.Function):
+    """Softmax cross-entropy with class weights or focal modulation on [B,n] or [B,n,...] fp32 logits."""
+
+    @staticmethod
+    def forward(ctx, logits, target, class_weights, focal, alpha, gamma, reduction):
+        logits = logits.float().contiguous()
+        target = target.long().contiguous()
+        B, n = logits.shape[0], logits.shape[1]
+        P = logits[0, 0].numel() if logits.dim() > 2 else 1
+        assert target.numel() == B * P, (target.shape, logits.shape)
+        dev = logits.device
+        cw = class_weights.detach().float().contiguous().to(dev) if class_weights is not None else None
+        rows = max(1, min(1024, (B * P + 1023) // 1024))
+        partial = torch.empty((rows, 2), dtype=torch.float32, device=dev)
+        out = torch.empty((2,), dtype=torch.float32, device=dev)
+        per = torch.empty(target.shape, dtype=torch.float32, device=dev) if reduction == "none" else None
+        lib().mia_ce_general_fwd(_p(logits), n * P, P, 1, _p(target), B, P, n, _p(cw), int(focal), float(alpha),
+                                 float(gamma), 1 if reduction == "mean" else 0, _p(per), _p(partial), rows, _p(out),
+                                 _stream())
+        ctx.meta = (B, P, n, int(focal), float(alpha), float(gamma), reduction)
+        ctx.save_for_backward(logits, target, cw, out)
+        return per if reduction == "none" else out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, cw, out = ctx.saved_tensors
+        B, P, n, focal, alpha, gamma, reduction = ctx.meta
+        dl = torch.empty_like(logits)
+        per_elem = reduction == "none"
+        up = g.detach().float().contiguous() if per_elem else g.detach().float().reshape(1).contiguous()
+        lib().mia_ce_general_bwd(_p(logits), n * P, P, 1, _p(target), B, P, n, _p(cw), focal, alpha, gamma,
+                                 None if per_elem else _p(out), _p(up), 1 if per_elem else 0, _p(dl), _stream())
+        return dl, None, None, None, None, None, None
+
+
+def general_ce(logits, target, *, class_weights=None, focal=False, alpha=1.0, gamma=2.0, reduction="mean"):
+    if reduction not in ("mean", "sum", "none"):
+        raise ValueError(f"unknown reduction {reduction!r}")
+    return GeneralCEFn.apply(logits, target, class_weights, focal, alpha, gamma, reduction)

@@ -50,6 +50,34 @@ class CombinedSegmentationLoss(nn.Module):
                                 ce_weight=self.ce_weight, overlap_weight=self.dice_weight)
 
 
+class FocalLoss(nn.Module):
+    """loss.py:83-102: alpha * (1 - pt)^gamma * ce on class logits [B,n] or pixel logits [B,n,H,W]."""
+
+    def __init__(self, alpha: float = 1.0, gamma: float = 2.0, reduction: str = "mean"):
+        super().__init__()
+        self.alpha, self.gamma, self.reduction = alpha, gamma, reduction
+
+    def forward(self, predictions, targets):
+        # the reference treats every reduction other than 'mean' / 'sum' as "no reduction"
+        red = self.reduction if self.reduction in ("mean", "sum") else "none"
+        return seg_ops.general_ce(predictions, targets, focal=True, alpha=self.alpha, gamma=self.gamma, reduction=red)
+
+
+class WeightedCrossEntropyLoss(nn.Module):
+    """nn.CrossEntropyLoss(weight=class_weights) (loss.py:147): sum w[t]*ce / sum w[t]."""
+
+    def __init__(self, weight: torch.Tensor):
+        super().__init__()
+        self.register_buffer("weight", weight.detach().float().clone())
+
+    def forward(self, predictions, targets):
+        return seg_ops.general_ce(predictions, targets, class_weights=self.weight)
+
+
+def _classification_ce(weights):
+    return _DeviceCrossEntropy() if weights is None else WeightedCrossEntropyLoss(weights)
+
+
 class CombinedLoss(nn.Module):
     """loss.py:8-24."""
 
@@ -57,9 +85,7 @@ class CombinedLoss(nn.Module):
         super().__init__()
         self.task, self.num_classes = task, num_classes
         if task == "classification":
-            if weights is not None:
-                raise NotImplementedError("class-weighted classification cross-entropy is not built")
-            self.criterion = _DeviceCrossEntropy()
+            self.criterion = _classification_ce(weights)
         elif task == "segmentation":
             self.criterion = CombinedSegmentationLoss(num_classes=num_classes, weights=weights)
         else:
@@ -76,14 +102,14 @@ def _check_classes(predictions, num_classes):
 
 def get_loss_function(task: str, num_classes: int = None, loss_type: str = "default",
                       class_weights: Optional[torch.Tensor] = None):
-    """loss.py:139-160. The focal variants are not built (the default configuration never selects them)."""
-    if loss_type == "focal":
-        raise NotImplementedError("FocalLoss is not built in this package")
+    """loss.py:139-160."""
     if task == "classification":
-        if class_weights is not None:
-            raise NotImplementedError("class-weighted classification cross-entropy is not built")
-        return _DeviceCrossEntropy()
+        if loss_type == "focal":
+            return FocalLoss()
+        return _classification_ce(class_weights)
     if task == "segmentation":
+        if loss_type == "focal":
+            return FocalLoss()
         if loss_type == "dice":
             return DiceLoss(num_classes=num_classes)
         if loss_type == "iou":

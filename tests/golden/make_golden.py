@@ -129,6 +129,28 @@ def segmentation_goldens(ref):
             res[name + ".dlogits"] = lg.grad.numpy()
         np.savez_compressed(os.path.join(HERE, f"segloss_{tag}.npz"), **res)
 
+    # G11: the remaining loss variants of loss.py: FocalLoss (:83-102) on class logits and on pixel logits, and the
+    # class-weighted cross-entropy get_loss_function returns for classification (:143-147)
+    res = {}
+    for (tag, shape) in (("cls", (37, 4)), ("pix", (2, 3, 9, 11))):
+        n = shape[1]
+        logits = randn(81 + n, *shape, scale=2.0)
+        tshape = (shape[0],) if len(shape) == 2 else (shape[0],) + shape[2:]
+        target = torch.from_numpy(rng.integers(0, n, tshape).astype(np.int64))
+        weights = torch.from_numpy((0.5 + rng.random(n)).astype(np.float32))
+        res.update({f"{tag}.logits": logits.numpy(), f"{tag}.target": target.numpy(), f"{tag}.weights": weights.numpy()})
+        cases = {"focal": ref_loss.FocalLoss(), "focal_a05_g3_sum": ref_loss.FocalLoss(alpha=0.5, gamma=3.0, reduction="sum"),
+                 "wce": ref_loss.get_loss_function("classification", class_weights=weights)}
+        for name, crit in cases.items():
+            lg = logits.clone().requires_grad_(True)
+            loss = crit(lg, target)
+            loss.backward()
+            res[f"{tag}.{name}.loss"] = np.float64(loss.item())
+            res[f"{tag}.{name}.dlogits"] = lg.grad.numpy()
+        with torch.no_grad():
+            res[f"{tag}.focal_none"] = ref_loss.FocalLoss(reduction="none")(logits, target).numpy()
+    np.savez_compressed(os.path.join(HERE, "loss_variants.npz"), **res)
+
 
 def main():
     torch.manual_seed(0)

@@ -338,3 +338,33 @@ def test_segmentation_full_size_matches_oracle_fp32():
     assert lm.shape == (2, 2, 300, 300)
     assert rel(lm, lr) < 1e-4
     assert (lm.argmax(1).cpu() == lr.argmax(1)).float().mean().item() > 0.999
+
+
+@pytest.mark.parametrize("tag", ["cls", "pix"])
+def test_focal_and_weighted_ce_match_reference(tag):
+    """FocalLoss and the class-weighted cross-entropy of src/loss.py against values the reference's own classes gave
+    (tests/golden/loss_variants.npz) on class logits [B,n] and pixel logits [B,n,H,W]."""
+    from mia_amd.src.loss import FocalLoss, WeightedCrossEntropyLoss, get_loss_function
+    gold = np.load(os.path.join(G, "loss_variants.npz"))
+    logits, target = torch.from_numpy(gold[f"{tag}.logits"]).cuda(), torch.from_numpy(gold[f"{tag}.target"]).cuda()
+    weights = torch.from_numpy(gold[f"{tag}.weights"]).cuda()
+    wce = get_loss_function("classification", class_weights=weights)
+    assert isinstance(wce, WeightedCrossEntropyLoss)
+    assert isinstance(get_loss_function("segmentation", num_classes=3, loss_type="focal"), FocalLoss)
+    cases = {"focal": FocalLoss(), "focal_a05_g3_sum": FocalLoss(alpha=0.5, gamma=3.0, reduction="sum"), "wce": wce}
+    for name, crit in cases.items():
+        z = logits.clone().requires_grad_(True)
+        loss = crit(z, target)
+        loss.backward()
+        ref = float(gold[f"{tag}.{name}.loss"])
+        assert abs(loss.item() - ref) <= 1e-5 * max(1.0, abs(ref)), name
+        assert rel(z.grad, gold[f"{tag}.{name}.dlogits"]) < 1e-4, name
+    z = logits.clone().requires_grad_(True)
+    per = FocalLoss(reduction="none")(z, target)
+    assert per.shape == target.shape and rel(per, gold[f"{tag}.focal_none"]) < 1e-5
+    up = randn(91, *per.shape).cuda()
+    (per * up).sum().backward()
+    z2 = logits.clone().cpu().requires_grad_(True)
+    ce = F.cross_entropy(z2, target.cpu(), reduction="none")
+    ((1 - torch.exp(-ce)) ** 2 * ce * up.cpu()).sum().backward()
+    assert rel(z.grad, z2.grad) < 1e-4
