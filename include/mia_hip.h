@@ -178,6 +178,10 @@ int mia_stem_im2col(int dtype, const float* x, int B, int H, int W, void* col, v
 /* fp32 master weight [R][Cc] -> compute-dtype copy [R][ldd] and/or transpose [Cc][ldt], zero padded. */
 int mia_cast_pad_transpose(int dtype, const float* src, int R, int Cc, void* dst, int ldd, void* dstT, int ldt,
                            void* stream);
+/* The same for n matrices in one launch per 48 (all 1x1-conv weights of a step). The arrays are HOST arrays of
+ * device pointers / sizes; dst[k] or dstT[k] may be NULL. */
+int mia_cast_pad_transpose_multi(int dtype, int n, const void* const* src, const int* rows, const int* cols,
+                                 void* const* dst, const int* ldd, void* const* dstT, const int* ldt, void* stream);
 
 /* ---- preprocessing: A.Resize + A.Normalize + ToTensorV2 (src/dataset.py:247-251, inference.py:116-140) and the
  *      no-transform fallback cv2.resize + /255 (src/dataset.py:180-182). src u8 [N,h,w,ch] (ch 1 or 3) ->

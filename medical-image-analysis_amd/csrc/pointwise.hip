@@ -947,3 +947,73 @@ extern "C" int mia_cast_pad_transpose(int dtype, const float* src, int R, int Cc
     MIA_CHECK_LAUNCH("mia_cast_pad_transpose");
     return 0;
 }
+
+// The same for many matrices in one launch (all the 1x1-conv weights of a step): descriptors travel by value in the
+// kernel arguments, 48 matrices per launch; a workgroup handles 4096 consecutive output elements of one matrix.
+#define CAST_MAXT 48
+#define CAST_BLOCK_ELEMS 4096
+struct CastChunk {
+    const float* src[CAST_MAXT];
+    void* dst[CAST_MAXT];
+    void* dstT[CAST_MAXT];
+    int R[CAST_MAXT], Cc[CAST_MAXT], ldd[CAST_MAXT], ldt[CAST_MAXT];
+    int first_block[CAST_MAXT + 1];
+    int n;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_pad_transpose_multi_kernel(CastChunk ch) {
+    int t = 0;
+    while (t + 1 < ch.n && (int)blockIdx.x >= ch.first_block[t + 1]) ++t;   // uniform per workgroup
+    const float* src = ch.src[t];
+    T* dst = reinterpret_cast<T*>(ch.dst[t]);
+    T* dstT = reinterpret_cast<T*>(ch.dstT[t]);
+    const int R = ch.R[t], Cc = ch.Cc[t], ldd = ch.ldd[t], ldt = ch.ldt[t];
+    const long long n1 = dst ? (long long)R * ldd : 0, n2 = dstT ? (long long)Cc * ldt : 0;
+    const long long base = (long long)(blockIdx.x - ch.first_block[t]) * CAST_BLOCK_ELEMS;
+    for (int e = threadIdx.x; e < CAST_BLOCK_ELEMS; e += 256) {
+        const long long i = base + e;
+        if (i >= n1 + n2) break;
+        if (i < n1) {
+            const int r = (int)(i / ldd), c = (int)(i % ldd);
+            dst[i] = from_f32<T>(c < Cc ? src[(size_t)r * Cc + c] : 0.f);
+        } else {
+            const long long k = i - n1;
+            const int c = (int)(k / ldt), r = (int)(k % ldt);
+            dstT[k] = from_f32<T>(r < R ? src[(size_t)r * Cc + c] : 0.f);
+        }
+    }
+}
+
+extern "C" int mia_cast_pad_transpose_multi(int dtype, int n, const void* const* src, const int* rows, const int* cols,
+                                            void* const* dst, const int* ldd, void* const* dstT, const int* ldt,
+                                            void* stream) {
+    MIA_CHECK_ARG(n > 0 && src && rows && cols && dst && ldd && dstT && ldt, "mia_cast_pad_transpose_multi: bad arguments");
+    MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "mia_cast_pad_transpose_multi: bad dtype %d", dtype);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    for (int t0 = 0; t0 < n; t0 += CAST_MAXT) {
+        CastChunk ch;
+        ch.n = (n - t0) < CAST_MAXT ? (n - t0) : CAST_MAXT;
+        int blocks = 0;
+        for (int i = 0; i < ch.n; ++i) {
+            const int k = t0 + i;
+            MIA_CHECK_ARG(src[k] && rows[k] > 0 && cols[k] > 0 && (dst[k] || dstT[k]),
+                          "mia_cast_pad_transpose_multi: matrix %d: bad arguments", k);
+            MIA_CHECK_ARG((!dst[k] || ldd[k] >= cols[k]) && (!dstT[k] || ldt[k] >= rows[k]),
+                          "mia_cast_pad_transpose_multi: matrix %d: leading dims too small", k);
+            ch.src[i] = reinterpret_cast<const float*>(src[k]);
+            ch.dst[i] = dst[k]; ch.dstT[i] = dstT[k];
+            ch.R[i] = rows[k]; ch.Cc[i] = cols[k]; ch.ldd[i] = ldd[k]; ch.ldt[i] = ldt[k];
+            ch.first_block[i] = blocks;
+            const long long elems = (dst[k] ? (long long)rows[k] * ldd[k] : 0) + (dstT[k] ? (long long)cols[k] * ldt[k] : 0);
+            blocks += (int)((elems + CAST_BLOCK_ELEMS - 1) / CAST_BLOCK_ELEMS);
+        }
+        ch.first_block[ch.n] = blocks;
+        if (dtype == MIA_BF16)
+            hipLaunchKernelGGL(cast_pad_transpose_multi_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, ch);
+        else
+            hipLaunchKernelGGL(cast_pad_transpose_multi_kernel<float>, dim3(blocks), dim3(256), 0, s, ch);
+    }
+    MIA_CHECK_LAUNCH("mia_cast_pad_transpose_multi");
+    return 0;
+}

@@ -315,6 +315,69 @@ def cast_weight(w2d, dtype, *, pad_to=None, want=True, want_t=False):
     return dst, dstT
 
 
+class WeightCaster:
+    """All weight casts of one forward in one or two launches (mia_cast_pad_transpose_multi) instead of one per
+    matrix. Built once for a fixed list of fp32 master matrices; every call writes the compute-dtype copies (and,
+    for the backward, their transposes) into one fresh flat buffer and returns per-matrix views.
+    specs: list of (w2d fp32 [R, Cc] contiguous view of a parameter, want copy, want transpose, pad_to or None)."""
+
+    def __init__(self, specs, dtype):
+        self.dtype = dtype
+        self.specs = specs
+        self.key = tuple((w.data_ptr(), tuple(w.shape), want, want_t, pad) for (w, want, want_t, pad) in specs)
+        esz_align = 64
+        self.items = []   # (index into specs, R, Cc, ld or 0, offset of copy or -1, offset of transpose or -1)
+        off = 0
+        for i, (w, want, want_t, pad) in enumerate(specs):
+            R, Cc = w.shape
+            ld = pad or Cc
+            alias = want and dtype == torch.float32 and ld == Cc      # the fp32 master itself serves as the copy
+            o1 = o2 = -1
+            if want and not alias:
+                o1 = off
+                off += (R * ld + esz_align - 1) // esz_align * esz_align
+            if want_t:
+                o2 = off
+                off += (Cc * R + esz_align - 1) // esz_align * esz_align
+            self.items.append((i, R, Cc, ld, o1, o2, alias))
+        self.total = off
+        self.work = [it for it in self.items if it[4] >= 0 or it[5] >= 0]
+        n = len(self.work)
+        self.n = n
+        if n:
+            vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
+            self.src = vp(*[specs[it[0]][0].data_ptr() for it in self.work])
+            self.rows = ip(*[it[1] for it in self.work])
+            self.cols = ip(*[it[2] for it in self.work])
+            self.ldd = ip(*[it[3] for it in self.work])
+            self.ldt = ip(*[it[1] for it in self.work])
+            self.dst, self.dstT = vp(), vp()
+
+    def matches(self, specs):
+        return len(specs) == len(self.specs) and self.key == tuple(
+            (w.data_ptr(), tuple(w.shape), want, want_t, pad) for (w, want, want_t, pad) in specs)
+
+    def __call__(self):
+        """-> list of (copy or None, transpose or None), one per spec."""
+        out = [None] * len(self.specs)
+        if self.n == 0:
+            return [(w if want else None, None) for (w, want, _, _) in self.specs]
+        dev = self.specs[0][0].device
+        flat = torch.empty((self.total,), dtype=self.dtype, device=dev)
+        base, esz = flat.data_ptr(), flat.element_size()
+        for k, (i, R, Cc, ld, o1, o2, alias) in enumerate(self.work):
+            self.dst[k] = base + o1 * esz if o1 >= 0 else None
+            self.dstT[k] = base + o2 * esz if o2 >= 0 else None
+        lib().mia_cast_pad_transpose_multi(_DT[self.dtype], self.n, self.src, self.rows, self.cols, self.dst, self.ldd,
+                                           self.dstT, self.ldt, _stream())
+        for (i, R, Cc, ld, o1, o2, alias) in self.items:
+            w, want, want_t, _ = self.specs[i]
+            c = w if alias else (flat[o1:o1 + R * ld].view(R, ld) if o1 >= 0 else None)
+            t = flat[o2:o2 + Cc * R].view(Cc, R) if o2 >= 0 else None
+            out[i] = (c, t)
+        return out
+
+
 # ------------------------------------------------------------------------------------------------
 # block-level autograd Functions. Inputs/outputs are NHWC tensors in the compute dtype.
 # `cfg` is a small python object carried outside autograd (BN buffers, geometry, flags).
@@ -369,7 +432,8 @@ class MBConvFn(torch.autograd.Function):
         # ---- expansion (ir only) ----
         if cfg.kind == "ir":
             M = B * H * W
-            wexp, wexpT = cast_weight(_w2d(w_exp), dt, want_t=need_bwd)   # [Cm, Cin] and, for the backward, [Cin, Cm]
+            # [Cm, Cin] and, for the backward, [Cin, Cm]; cast by the trunk in one launch for all blocks when it can
+            wexp, wexpT = cfg.pre["exp"] if cfg.pre else cast_weight(_w2d(w_exp), dt, want_t=need_bwd)
             y1, part = gemm_nt(x.view(M, Cin), wexp, stats_rows=part_rows((M + 63) // 64) if training else 0)
             st1 = bn_finalize_fwd(part, M, cfg.bn_exp)
             y1 = y1.view(B, H, W, -1)
@@ -389,10 +453,10 @@ class MBConvFn(torch.autograd.Function):
         # ---- squeeze-excite ----
         pool_part = img_colsum(y2, None, st2[0], st2[1], ACT_SILU)
         wr = _w2d(w_ser)
-        _, weT = cast_weight(_w2d(w_see), torch.float32, want=False, want_t=True)  # [RD, Cm]
+        _, weT = cfg.pre["se"] if cfg.pre else cast_weight(_w2d(w_see), torch.float32, want=False, want_t=True)  # [RD, Cm]
         pooled, hpre, gate = se_gate_fwd(pool_part, OH * OW, wr, b_ser.detach(), weT, b_see.detach())
         # ---- projection ----
-        wproj, wprojT = cast_weight(_w2d(w_proj), dt, want_t=need_bwd)   # [Co, Cm] and [Cm, Co]
+        wproj, wprojT = cfg.pre["proj"] if cfg.pre else cast_weight(_w2d(w_proj), dt, want_t=need_bwd)   # [Co, Cm], [Cm, Co]
         y3, part = gemm_nt(y2.view(M2, Cm), wproj, pscale=st2[0], pshift=st2[1], pro_act=ACT_SILU, gate=gate,
                            rows_per_img=OH * OW, stats_rows=part_rows((M2 + 63) // 64) if training else 0)
         st3 = bn_finalize_fwd(part, M2, cfg.bn_proj)

@@ -4,6 +4,7 @@ gfx950 kernels. Parameter containers are ordinary nn.Conv2d / nn.BatchNorm2d obj
 keys, shapes and initialisation match timm's; their forward() is never called.
 """
 import math
+import weakref
 from typing import List
 
 import torch
@@ -28,6 +29,11 @@ B3_FEATURE_DIMS = [24, 32, 48, 136, 384]
 
 class _Cfg:
     pass
+
+
+# per-trunk launch tables of the batched weight cast (ctypes arrays: kept off the module so that copying or pickling a
+# model never meets them)
+_CASTERS = weakref.WeakKeyDictionary()
 
 
 class SqueezeExcite(nn.Module):
@@ -60,9 +66,18 @@ class MBConv(nn.Module):
             self.conv_pw = nn.Conv2d(cin, cout, 1, bias=False)
             self.bn2 = nn.BatchNorm2d(cout)
 
-    def forward(self, x):
+    def weight_specs(self, want_t):
+        """(matrix, want copy, want transpose, pad) per GEMM weight, in the order (expand,) project, SE-expand; the
+        first entries are cast to the compute dtype, the SE one stays fp32 (transposed only)."""
+        w2 = ops._w2d
+        gemm = ([(w2(self.conv_pw.weight), True, want_t, None), (w2(self.conv_pwl.weight), True, want_t, None)]
+                if self.kind == "ir" else [(w2(self.conv_pw.weight), True, want_t, None)])
+        return gemm, (w2(self.se.conv_expand.weight), False, True, None)
+
+    def forward(self, x, pre=None):
         cfg = _Cfg()
         cfg.kind, cfg.k, cfg.s, cfg.has_skip = self.kind, self.k, self.s, self.has_skip
+        cfg.pre = pre
         se = self.se
         if self.kind == "ir":
             cfg.bn_exp, cfg.bn_dw, cfg.bn_proj = ops.BNState(self.bn1), ops.BNState(self.bn2), ops.BNState(self.bn3)
@@ -109,14 +124,41 @@ class EfficientNetB3Features(nn.Module):
                 nn.init.ones_(m.weight)
                 nn.init.zeros_(m.bias)
 
+    def _cast_block_weights(self):
+        """Every block's GEMM weights in the compute dtype (+ transposes when a backward will follow) and the SE
+        expand weights transposed, in two launches for the whole trunk. -> one dict per block, in block order."""
+        want_t = torch.is_grad_enabled()
+        blocks = [blk for stage in self.blocks for blk in stage]
+        gemm_specs, se_specs, spans = [], [], []
+        for blk in blocks:
+            g, s_ = blk.weight_specs(want_t)
+            spans.append((len(gemm_specs), len(g)))
+            gemm_specs += g
+            se_specs.append(s_)
+        key = (self.compute_dtype, want_t)
+        casters = _CASTERS.setdefault(self, {})
+        cached = casters.get(key)
+        if cached is None or not cached[0].matches(gemm_specs) or not cached[1].matches(se_specs):
+            cached = (ops.WeightCaster(gemm_specs, self.compute_dtype), ops.WeightCaster(se_specs, torch.float32))
+            casters[key] = cached
+        gw, sw = cached[0](), cached[1]()
+        out = []
+        for (start, n), se_w in zip(spans, sw):
+            d = {"se": se_w, "proj": gw[start + n - 1]}
+            if n == 2:
+                d["exp"] = gw[start]
+            out.append(d)
+        return out
+
     def forward_nhwc(self, x) -> List[torch.Tensor]:
         cfg = _Cfg()
         cfg.dtype, cfg.bn = self.compute_dtype, ops.BNState(self.bn1)
         h = ops.StemFn.apply(x, self.conv_stem.weight, self.bn1.weight, self.bn1.bias, cfg)
+        pre = iter(self._cast_block_weights())
         feats = []
         for si, stage in enumerate(self.blocks):
             for blk in stage:
-                h = blk(h)
+                h = blk(h, next(pre))
             if si in B3_FEATURE_STAGES:
                 feats.append(h)
         return feats
