@@ -17,6 +17,10 @@ class AdamW(torch.optim.Optimizer):
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}
+        # per-parameter step counts as Python ints. torch.optim.AdamW increments one CPU tensor per parameter and
+        # step (several hundred tiny host ops); here the parameters that share a count share ONE state["step"] tensor,
+        # made once per step
+        self._pstep = {}
 
     def _table(self, gi, ps):
         """ctypes pointer tables of one group, rebuilt only when the set of (param, grad) storages changes."""
@@ -49,15 +53,32 @@ class AdamW(torch.optim.Optimizer):
                     raise RuntimeError("mia_amd.optim.AdamW needs contiguous fp32 parameters on an MI355X device")
                 if not p.grad.is_contiguous():
                     p.grad = p.grad.contiguous()
+            by_step = {}
+            for p in ps:
                 st = self.state[p]
                 if not st:
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["step"] += 1
-            step = int(self.state[ps[0]]["step"].item())
-            n, tp, tg, tm, tv, sizes = self._table(gi, ps)
+                k = self._pstep.get(p)
+                if k is None:
+                    k = int(float(st["step"]))      # first step, or the first one after load_state_dict()
+                k += 1
+                self._pstep[p] = k
+                by_step.setdefault(k, []).append(p)
             b1, b2 = group["betas"]
-            lib().mia_adamw_step(n, tp, tg, tm, tv, sizes, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                 float(group["weight_decay"]), step, float(grad_scale), _stream())
+            # parameters that joined later (unfrozen for fine-tuning) carry their own step count, as in torch: one
+            # launch per distinct count (a single launch in the usual case)
+            for si, (k, plist) in enumerate(sorted(by_step.items())):
+                shared = torch.tensor(float(k))
+                for p in plist:
+                    self.state[p]["step"] = shared
+                n, tp, tg, tm, tv, sizes = self._table((gi, si), plist)
+                lib().mia_adamw_step(n, tp, tg, tm, tv, sizes, float(group["lr"]), float(b1), float(b2),
+                                     float(group["eps"]), float(group["weight_decay"]), k, float(grad_scale), _stream())
         return loss
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._pstep.clear()     # the loaded step tensors are read back at the next step()
+        self._tables.clear()

@@ -343,6 +343,27 @@ def test_adamw_matches_torch():
         assert relerr(mine.state[a]["exp_avg"], ref.state[b]["exp_avg"]) < 1e-6
         assert relerr(mine.state[a]["exp_avg_sq"], ref.state[b]["exp_avg_sq"]) < 1e-6
         assert int(mine.state[a]["step"]) == 5
+    # a parameter that starts receiving gradients later (unfrozen for fine-tuning) keeps its own step count, and the
+    # step tensors of a state dict are right; a reloaded optimizer continues identically
+    late_m, late_r = torch.nn.Parameter(rnd(33, seed=7)), None
+    late_r = torch.nn.Parameter(late_m.detach().clone())
+    mine.add_param_group({"params": [late_m]})
+    ref.add_param_group({"params": [late_r]})
+    for step in range(3):
+        for i, (a, b) in enumerate(zip(mine_p + [late_m], ref_p + [late_r])):
+            g = rnd(*a.shape, seed=5000 * (step + 1) + i)
+            a.grad, b.grad = g.clone(), g.clone()
+        mine.step()
+        ref.step()
+        if step == 0:
+            sd = mine.state_dict()
+            assert {int(v["step"]) for v in sd["state"].values()} == {6, 1}
+            mine2 = AdamW([{"params": mine_p}, {"params": [late_m]}], lr=1e-3, weight_decay=1e-4)
+            mine2.load_state_dict(sd)
+            mine = mine2
+    for a, b in zip(mine_p + [late_m], ref_p + [late_r]):
+        assert relerr(a, b) < 2e-6
+    assert int(mine.state_dict()["state"][len(mine_p)]["step"]) == 3 and int(mine.state_dict()["state"][0]["step"]) == 8
     # scheduler compatibility: lr lives in param_groups
     sch = torch.optim.lr_scheduler.ReduceLROnPlateau(mine, mode="min", factor=0.5, patience=0)
     sch.step(1.0); sch.step(2.0)
