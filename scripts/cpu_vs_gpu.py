@@ -12,7 +12,8 @@ torch.manual_seed(0)
 model = FoundationModel(backbone="efficientnet_b3", pretrained=False, dropout=0.2, classification_heads={"synthetic": 4},
                         use_attention=True, compute_dtype="bf16").to(dev).train()
 reducer = GradReducer(model.parameters())
-opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+from mia_amd.optim import AdamW
+opt = AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 x = torch.randn(B, 3, 300, 300, device=dev)
 y = torch.randint(0, 4, (B,), device=dev)
