@@ -24,11 +24,11 @@ def _p(t: Optional[torch.Tensor]):
     if not t.is_cuda:
         raise RuntimeError("mia_amd kernels need tensors on an MI355X device; there is no CPU path "
                            f"(got a {t.device} tensor of shape {tuple(t.shape)})")
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()     # a plain int: the prototypes declare void*, ctypes converts without a wrapper object
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _require_cuda(t: torch.Tensor):
