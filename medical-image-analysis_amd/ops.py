@@ -27,7 +27,15 @@ def _p(t: Optional[torch.Tensor]):
     return t.data_ptr()     # a plain int: the prototypes declare void*, ctypes converts without a wrapper object
 
 
+# torch.cuda.current_stream() builds a Stream object through several Python layers (~8 us a call, once per kernel
+# launch: half of a step's host time); the raw handle is one C call away
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
