@@ -145,26 +145,33 @@ int mia_cbam_bwd(int dtype, const void* dx2, const void* x, int B, int H, int W,
 /* ---- multi-head self-attention core (MultiHeadAttentionClassifier.forward, model.py:153-163) --------------------
  * qkv [B*HW, 3C] (query | key | value projections, head h = columns h*HD..) -> out [B*HW, C];
  * softmax(QK^T/sqrt(HD)) is written to P [B,heads,HW,HW] (fp32) for the backward; dropout(pdrop) on the weights
- * uses a counter-based mask from `seed` that the backward regenerates. HW <= 256, HD in {8,16,32,48,64}. */
+ * uses a counter-based mask from `seed` that the backward regenerates. HW <= 256, HD in {8,16,32,48,64}.
+ * seed_offset (nullable, here and in every entry point that takes a seed): a counter in DEVICE memory added to the
+ * seed (times an odd constant) at launch time, so that a captured HIP graph, which replays fixed arguments, draws
+ * new masks on every replay when the caller rewrites the counter before it (mia_set_words). */
 int mia_attention_fwd(int dtype, const void* qkv, int B, int HW, int C, int heads, float pdrop,
-                      unsigned long long seed, float* P, void* out, void* stream);
+                      unsigned long long seed, const unsigned long long* seed_offset, float* P, void* out, void* stream);
 /* out: the forward's output (the row sums of P o dP are formed as dout . out). */
 int mia_attention_bwd(int dtype, const void* qkv, const float* P, const void* dout, const void* out, int B, int HW,
-                      int C, int heads, float pdrop, unsigned long long seed, void* dqkv, void* stream);
+                      int C, int heads, float pdrop, unsigned long long seed, const unsigned long long* seed_offset,
+                      void* dqkv, void* stream);
 
 /* ---- classifier front end: AdaptiveAvgPool2d(1) -> Flatten -> [LayerNorm] -> Dropout (model.py:134-137, :309-311)
  * in_part [B][S][C]: per-image channel sums over H*W (mia_img_colsum). gamma/beta NULL = no LayerNorm. */
 int mia_pool_ln_dropout_fwd(const float* in_part, int B, int S, int HW, int C, const float* gamma, const float* beta,
-                            float eps, float pdrop, unsigned long long seed, float* out, float* xhat, float* rstd,
+                            float eps, float pdrop, unsigned long long seed, const unsigned long long* seed_offset,
+                            float* out, float* xhat, float* rstd,
                             void* stream);
 int mia_pool_ln_dropout_bwd(const float* dout, int B, int C, const float* gamma, const float* xhat, const float* rstd,
-                            float pdrop, unsigned long long seed, float* dpooled, float* dgamma_rows,
+                            float pdrop, unsigned long long seed, const unsigned long long* seed_offset, float* dpooled,
+                            float* dgamma_rows,
                             float* dbeta_rows, void* stream);
 /* out[b,p,c] = v[b,c]*mult (+ res[b,p,c]): gradient of the average pool spread back over H*W. */
 int mia_broadcast_rows(int dtype, const float* v, int B, int HW, int C, float mult, const void* res, void* out,
                        void* stream);
 /* x *= dropout mask (and zero where relu_ref <= 0): nn.Dropout after nn.ReLU, forward and backward. */
-int mia_dropout_f32(float* x, const float* relu_ref, long long n, float pdrop, unsigned long long seed, void* stream);
+int mia_dropout_f32(float* x, const float* relu_ref, long long n, float pdrop, unsigned long long seed,
+                    const unsigned long long* seed_offset, void* stream);
 /* out[c] = sum_r x[r][c]: bias gradients. */
 int mia_colsum(int dtype, const void* x, long long R, int C, int ld, float* out, void* stream);
 /* nn.CrossEntropyLoss (src/loss.py:147; train.py:352): mean loss and d loss / d logits (zero padded to ldd columns). */
@@ -202,10 +209,17 @@ int mia_gather_slices(const void* vol, int elem_bytes, long long n_slices, long 
  * One multi-tensor pass over (param, grad, exp_avg, exp_avg_sq), all fp32 and contiguous. params/grads/exp_avg/
  * exp_avg_sq are HOST arrays of n_tensors DEVICE pointers, sizes a host array of element counts; step is the 1-based
  * number of this update; gradients are multiplied by grad_scale first. Arithmetic = torch's AdamW step:
- * p *= 1-lr*wd; m = lerp(m,g,1-b1); v = b2*v+(1-b2)*g*g; p -= lr/(1-b1^t) * m/(sqrt(v)/sqrt(1-b2^t)+eps). */
+ * p *= 1-lr*wd; m = lerp(m,g,1-b1); v = b2*v+(1-b2)*g*g; p -= lr/(1-b1^t) * m/(sqrt(v)/sqrt(1-b2^t)+eps).
+ * dev_hyper (nullable): 3 floats in DEVICE memory {1-lr*wd, lr/(1-b1^t), 1/sqrt(1-b2^t)} read at run time in place
+ * of the values derived from lr, weight_decay and step, for launches replayed from a captured HIP graph. */
 int mia_adamw_step(int n_tensors, const void* const* params, const void* const* grads, const void* const* exp_avg,
                    const void* const* exp_avg_sq, const long long* sizes, double lr, double beta1, double beta2,
-                   double eps, double weight_decay, int step, double grad_scale, void* stream);
+                   double eps, double weight_decay, int step, double grad_scale, const float* dev_hyper,
+                   void* stream);
+/* Stores n (<= 64) 32-bit words, passed by value in the launch, to device memory dst. No counterpart in the
+ * reference: it refreshes the per-step words a replayed graph reads (seed_offset, dev_hyper) without a host buffer
+ * that must stay untouched until an asynchronous copy has run. */
+int mia_set_words(void* dst, int n, const unsigned* host_words, void* stream);
 
 /* ---- segmentation decoders (src/model.py:179-237 EnhancedUNetDecoder, :417-468 UNetDecoder, :471-494
  *      DecoderBlock) and losses (src/loss.py:27-80 CombinedSegmentationLoss/DiceLoss, :105-136 IoULoss) ----------
@@ -232,7 +246,8 @@ int mia_pixel_linear_fwd(int dtype, const void* x, int B, int HW, int C, int n, 
 int mia_pixel_linear_bwd(int dtype, const void* x, const float* dlogits, int B, int HW, int C, int n, const float* Wt,
                          void* dx, float* partial, int partial_rows, void* stream);
 /* nn.Dropout2d mask (model.py:481): mask[b][c] = 0 with probability p, else 1/(1-p); counter-based, from seed. */
-int mia_channel_dropout_mask(float* mask, int B, int C, float p, unsigned long long seed, void* stream);
+int mia_channel_dropout_mask(float* mask, int B, int C, float p, unsigned long long seed,
+                             const unsigned long long* seed_offset, void* stream);
 /* loss = ce_weight * CrossEntropy(logits, target, weight=class_weights) + overlap_weight * (1 - mean score),
  * score = Dice (iou = 0) or IoU (iou = 1) per (image, class) on softmax probabilities. logits [B][n][HW] fp32,
  * target [B][HW] int64, n <= 8. partial: [B*splits][3n+2] scratch; coef: [1 + 2*B*n] kept for the backward. */

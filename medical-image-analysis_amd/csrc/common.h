@@ -210,5 +210,20 @@ __device__ __forceinline__ float wave_max(float v) {
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Zero fill of n 32-bit words by a kernel. hipMemsetAsync is not used on the kernels' stream: inside a captured HIP
+// graph it becomes a memset node, and the replays of such nodes were observed not to clear the range again (results
+// were right on the first replay only, while the memory was still fresh), whereas a kernel node replays like the rest.
+static __global__ __launch_bounds__(256) void mia_zero_words_kernel(unsigned* __restrict__ p, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = 0u;
+}
+
+static inline hipError_t mia_zero_words(void* p, long long n_words, hipStream_t s) {
+    if (n_words <= 0) return hipSuccess;
+    long long blocks = (n_words + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(mia_zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (unsigned*)p, n_words);
+    return hipGetLastError();
+}
+
 enum { MIA_F32 = 0, MIA_BF16 = 1 };
 enum { MIA_ACT_NONE = 0, MIA_ACT_SILU = 1, MIA_ACT_RELU = 2 };

@@ -646,8 +646,8 @@ extern "C" int mia_dwconv_fwd(int dtype, const void* x, int B, int H, int W, int
     if (stats) {
         if (gx > part_rows) gx = part_rows;
         if (gx < part_rows) {  // rows no workgroup owns must still read as zero
-            hipError_t e = hipMemsetAsync(stats + (size_t)gx * 2 * C, 0, (size_t)(part_rows - gx) * 2 * C * sizeof(float), s);
-            MIA_CHECK_ARG(e == hipSuccess, "mia_dwconv_fwd: memset failed: %s", hipGetErrorString(e));
+            hipError_t e = mia_zero_words(stats + (size_t)gx * 2 * C, (long long)(part_rows - gx) * 2 * C, s);
+            MIA_CHECK_ARG(e == hipSuccess, "mia_dwconv_fwd: zero fill failed: %s", hipGetErrorString(e));
         }
     }
     int rc = dtype == MIA_BF16 ? dispatch_tile<bf16_t>(p, K, S, gx, s) : dispatch_tile<float>(p, K, S, gx, s);
@@ -682,8 +682,8 @@ extern "C" int mia_dwconv_bwd_data(int dtype, const void* dy, int B, int H, int 
         if (stats) {
             if (gx > part_rows) gx = part_rows;
             if (gx < part_rows) {
-                hipError_t e = hipMemsetAsync(stats + (size_t)gx * 2 * C, 0, (size_t)(part_rows - gx) * 2 * C * sizeof(float), s);
-                MIA_CHECK_ARG(e == hipSuccess, "mia_dwconv_bwd_data: memset failed: %s", hipGetErrorString(e));
+                hipError_t e = mia_zero_words(stats + (size_t)gx * 2 * C, (long long)(part_rows - gx) * 2 * C, s);
+                MIA_CHECK_ARG(e == hipSuccess, "mia_dwconv_bwd_data: zero fill failed: %s", hipGetErrorString(e));
             }
         }
         int rc = dtype == MIA_BF16 ? dispatch_tile<bf16_t>(p, K, 1, gx, s) : dispatch_tile<float>(p, K, 1, gx, s);
@@ -698,8 +698,8 @@ extern "C" int mia_dwconv_bwd_data(int dtype, const void* dy, int B, int H, int 
         if (stats) {
             if (gx > part_rows) gx = part_rows;
             if (gx < part_rows) {
-                hipError_t e = hipMemsetAsync(stats + (size_t)gx * 2 * C, 0, (size_t)(part_rows - gx) * 2 * C * sizeof(float), s);
-                MIA_CHECK_ARG(e == hipSuccess, "mia_dwconv_bwd_data: memset failed: %s", hipGetErrorString(e));
+                hipError_t e = mia_zero_words(stats + (size_t)gx * 2 * C, (long long)(part_rows - gx) * 2 * C, s);
+                MIA_CHECK_ARG(e == hipSuccess, "mia_dwconv_bwd_data: zero fill failed: %s", hipGetErrorString(e));
             }
         }
         const size_t lds = (size_t)K * K * p.CB * 4 + 256 * 8 * 4 + (size_t)(p.TH + 2) * (p.TW + 2) * p.CB * elem;

@@ -8,6 +8,13 @@
 // ------------------------------------------------------------------------------------------------
 // counter-based dropout mask: keep iff hash(seed, idx) >= p.  Recomputed, never stored.
 // ------------------------------------------------------------------------------------------------
+// Effective seed of a launch: the host's seed plus an optional counter that lives in device memory. A captured HIP
+// graph replays the same kernel arguments every time; the counter (bumped once per replay by a kernel of the graph)
+// is what makes each replay draw new masks, while forward and backward of one replay still agree.
+__device__ __forceinline__ unsigned long long seed_with_offset(unsigned long long seed, const unsigned long long* off) {
+    return off ? seed + off[0] * 0x9E3779B97F4A7C15ull : seed;
+}
+
 __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned long long idx, float p) {
     if (p <= 0.f) return 1.f;
     unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
@@ -529,7 +536,8 @@ __global__ __launch_bounds__(256) void cbam_bwd_dx_kernel(const T* dx2, const fl
 // ------------------------------------------------------------------------------------------------
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attention_fwd_kernel(const T* qkv, int HW, int C, int heads, float scale,
-                                                            float pdrop, unsigned long long seed, float* P, T* out) {
+                                                            float pdrop, unsigned long long seed, const unsigned long long* seed_off, float* P, T* out) {
+    seed = seed_with_offset(seed, seed_off);
     extern __shared__ float sm[];
     float* Ks = sm;             // [HW][HD]
     float* Vs = sm + HW * HD;   // [HW][HD]
@@ -582,7 +590,8 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const T* qkv, int HW
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* qkv, const float* P, const T* dout, const T* out,
                                                             int HW, int C, int heads, float scale, float pdrop,
-                                                            unsigned long long seed, T* dqkv) {
+                                                            unsigned long long seed, const unsigned long long* seed_off, T* dqkv) {
+    seed = seed_with_offset(seed, seed_off);
     extern __shared__ float sm[];
     float* As = sm;             // phase A: K ; phase B: Q
     float* Bs = sm + HW * HD;   // phase A: V ; phase B: dO
@@ -676,8 +685,9 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* qkv, const 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pool_ln_dropout_fwd_kernel(const float* in_part, int B, int S, int C,
                                                                   float inv_hw, const float* gamma, const float* beta,
-                                                                  float eps, float pdrop, unsigned long long seed,
+                                                                  float eps, float pdrop, unsigned long long seed, const unsigned long long* seed_off,
                                                                   float* out, float* xhat, float* rstd_out) {
+    seed = seed_with_offset(seed, seed_off);
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -715,8 +725,9 @@ __global__ __launch_bounds__(256) void pool_ln_dropout_fwd_kernel(const float* i
 // backward: dpooled [B,C] from dout [B,C]; per-image partial dgamma/dbeta rows are summed by a colsum afterwards
 __global__ __launch_bounds__(256) void pool_ln_dropout_bwd_kernel(const float* dout, int B, int C, const float* gamma,
                                                                   const float* xhat, const float* rstd, float pdrop,
-                                                                  unsigned long long seed, float* dpooled,
+                                                                  unsigned long long seed, const unsigned long long* seed_off, float* dpooled,
                                                                   float* dgamma_rows, float* dbeta_rows) {
+    seed = seed_with_offset(seed, seed_off);
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -765,7 +776,8 @@ __global__ __launch_bounds__(256) void broadcast_rows_kernel(const float* v, int
 
 // y = x * dropout_mask (in place), optionally gated by (ref > 0): dropout forward, or ReLU+dropout backward
 __global__ __launch_bounds__(256) void dropout_f32_kernel(float* x, const float* relu_ref, long long n, float pdrop,
-                                                          unsigned long long seed) {
+                                                          unsigned long long seed, const unsigned long long* seed_off) {
+    seed = seed_with_offset(seed, seed_off);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         float v = x[i] * drop_scale(seed, (unsigned long long)i, pdrop);
         if (relu_ref && !(relu_ref[i] > 0.f)) v = 0.f;
@@ -994,7 +1006,8 @@ extern "C" int mia_cbam_bwd(int dtype, const void* dx2, const void* x, int B, in
 
 template <typename T>
 static int launch_attention(bool fwd, const void* qkv, const float* P, const void* dout, const void* o, int B, int HW, int C, int heads,
-                            float pdrop, unsigned long long seed, float* Pout, void* out, hipStream_t s) {
+                            float pdrop, unsigned long long seed, const unsigned long long* seed_off, float* Pout, void* out,
+                            hipStream_t s) {
     const int HD = C / heads;
     const float scale = 1.0f / sqrtf((float)HD);
     const size_t lds = ((size_t)2 * HW * HD + (fwd ? 0 : HW + (size_t)ATT_JC * HW)) * 4;
@@ -1004,11 +1017,11 @@ static int launch_attention(bool fwd, const void* qkv, const float* P, const voi
         if (fwd) {                                                                                                    \
             auto k = attention_fwd_kernel<T, HD_>;                                                                    \
             if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const T*)qkv, HW, C, heads, scale, pdrop, seed, Pout, (T*)out); \
+            hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const T*)qkv, HW, C, heads, scale, pdrop, seed, seed_off, Pout, (T*)out); \
         } else {                                                                                                      \
             auto k = attention_bwd_kernel<T, HD_>;                                                                    \
             if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const T*)qkv, P, (const T*)dout, (const T*)o, HW, C, heads, scale, pdrop, seed, (T*)out); \
+            hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const T*)qkv, P, (const T*)dout, (const T*)o, HW, C, heads, scale, pdrop, seed, seed_off, (T*)out); \
         }                                                                                                             \
     } while (0)
     if (HD == 48) MIA_ATT(48);
@@ -1031,48 +1044,52 @@ static int attention_checks(const char* name, int B, int HW, int C, int heads) {
 
 // qkv [B*HW, 3C] -> out [B*HW, C]; P [B,heads,HW,HW] fp32 softmax weights kept for the backward pass
 extern "C" int mia_attention_fwd(int dtype, const void* qkv, int B, int HW, int C, int heads, float pdrop,
-                                 unsigned long long seed, float* P, void* out, void* stream) {
+                                 unsigned long long seed, const unsigned long long* seed_offset, float* P, void* out,
+                                 void* stream) {
     if (attention_checks("mia_attention_fwd", B, HW, C, heads)) return -1;
     MIA_CHECK_ARG(qkv && P && out, "mia_attention_fwd: null");
     int rc = dtype == MIA_BF16
-                 ? launch_attention<bf16_t>(true, qkv, nullptr, nullptr, nullptr, B, HW, C, heads, pdrop, seed, P, out, MIA_STREAM)
-                 : launch_attention<float>(true, qkv, nullptr, nullptr, nullptr, B, HW, C, heads, pdrop, seed, P, out, MIA_STREAM);
+                 ? launch_attention<bf16_t>(true, qkv, nullptr, nullptr, nullptr, B, HW, C, heads, pdrop, seed, seed_offset, P, out, MIA_STREAM)
+                 : launch_attention<float>(true, qkv, nullptr, nullptr, nullptr, B, HW, C, heads, pdrop, seed, seed_offset, P, out, MIA_STREAM);
     MIA_CHECK_ARG(rc == 0, "mia_attention_fwd: dispatch failed");
     MIA_CHECK_LAUNCH("mia_attention_fwd");
     return 0;
 }
 
 extern "C" int mia_attention_bwd(int dtype, const void* qkv, const float* P, const void* dout, const void* out, int B,
-                                 int HW, int C, int heads, float pdrop, unsigned long long seed, void* dqkv,
+                                 int HW, int C, int heads, float pdrop, unsigned long long seed,
+                                 const unsigned long long* seed_offset, void* dqkv,
                                  void* stream) {
     if (attention_checks("mia_attention_bwd", B, HW, C, heads)) return -1;
     MIA_CHECK_ARG(qkv && P && dout && out && dqkv, "mia_attention_bwd: null");
     int rc = dtype == MIA_BF16
-                 ? launch_attention<bf16_t>(false, qkv, P, dout, out, B, HW, C, heads, pdrop, seed, nullptr, dqkv, MIA_STREAM)
-                 : launch_attention<float>(false, qkv, P, dout, out, B, HW, C, heads, pdrop, seed, nullptr, dqkv, MIA_STREAM);
+                 ? launch_attention<bf16_t>(false, qkv, P, dout, out, B, HW, C, heads, pdrop, seed, seed_offset, nullptr, dqkv, MIA_STREAM)
+                 : launch_attention<float>(false, qkv, P, dout, out, B, HW, C, heads, pdrop, seed, seed_offset, nullptr, dqkv, MIA_STREAM);
     MIA_CHECK_ARG(rc == 0, "mia_attention_bwd: dispatch failed");
     MIA_CHECK_LAUNCH("mia_attention_bwd");
     return 0;
 }
 
 extern "C" int mia_pool_ln_dropout_fwd(const float* in_part, int B, int S, int HW, int C, const float* gamma,
-                                       const float* beta, float eps, float pdrop, unsigned long long seed, float* out,
+                                       const float* beta, float eps, float pdrop, unsigned long long seed,
+                                       const unsigned long long* seed_offset, float* out,
                                        float* xhat, float* rstd, void* stream) {
     MIA_CHECK_ARG(in_part && out && xhat && rstd && B > 0 && S > 0 && HW > 0 && C > 0, "mia_pool_ln_dropout_fwd: bad arguments");
     MIA_CHECK_ARG(!(gamma == nullptr) == !(beta == nullptr), "mia_pool_ln_dropout_fwd: gamma/beta come together");
     hipLaunchKernelGGL(pool_ln_dropout_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, MIA_STREAM, in_part, B, S, C,
-                       1.0f / (float)HW, gamma, beta, eps, pdrop, seed, out, xhat, rstd);
+                       1.0f / (float)HW, gamma, beta, eps, pdrop, seed, seed_offset, out, xhat, rstd);
     MIA_CHECK_LAUNCH("mia_pool_ln_dropout_fwd");
     return 0;
 }
 
 extern "C" int mia_pool_ln_dropout_bwd(const float* dout, int B, int C, const float* gamma, const float* xhat,
-                                       const float* rstd, float pdrop, unsigned long long seed, float* dpooled,
+                                       const float* rstd, float pdrop, unsigned long long seed,
+                                       const unsigned long long* seed_offset, float* dpooled,
                                        float* dgamma_rows, float* dbeta_rows, void* stream) {
     MIA_CHECK_ARG(dout && dpooled && B > 0 && C > 0, "mia_pool_ln_dropout_bwd: bad arguments");
     MIA_CHECK_ARG(!gamma || (xhat && rstd && dgamma_rows && dbeta_rows), "mia_pool_ln_dropout_bwd: LayerNorm needs its state");
     hipLaunchKernelGGL(pool_ln_dropout_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, MIA_STREAM, dout, B, C, gamma, xhat, rstd,
-                       pdrop, seed, dpooled, dgamma_rows, dbeta_rows);
+                       pdrop, seed, seed_offset, dpooled, dgamma_rows, dbeta_rows);
     MIA_CHECK_LAUNCH("mia_pool_ln_dropout_bwd");
     return 0;
 }
@@ -1092,17 +1109,18 @@ extern "C" int mia_broadcast_rows(int dtype, const float* v, int B, int HW, int 
 }
 
 extern "C" int mia_dropout_f32(float* x, const float* relu_ref, long long n, float pdrop, unsigned long long seed,
+                               const unsigned long long* seed_offset,
                                void* stream) {
     MIA_CHECK_ARG(x && n > 0, "mia_dropout_f32: bad arguments");
-    hipLaunchKernelGGL(dropout_f32_kernel, dim3(grid1d(n)), dim3(256), 0, MIA_STREAM, x, relu_ref, n, pdrop, seed);
+    hipLaunchKernelGGL(dropout_f32_kernel, dim3(grid1d(n)), dim3(256), 0, MIA_STREAM, x, relu_ref, n, pdrop, seed, seed_offset);
     MIA_CHECK_LAUNCH("mia_dropout_f32");
     return 0;
 }
 
 extern "C" int mia_colsum(int dtype, const void* x, long long R, int C, int ld, float* out, void* stream) {
     MIA_CHECK_ARG(x && out && R > 0 && C > 0 && ld >= C, "mia_colsum: bad arguments");
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)C * sizeof(float), MIA_STREAM);
-    MIA_CHECK_ARG(e == hipSuccess, "mia_colsum: memset failed: %s", hipGetErrorString(e));
+    hipError_t e = mia_zero_words(out, C, MIA_STREAM);
+    MIA_CHECK_ARG(e == hipSuccess, "mia_colsum: zero fill failed: %s", hipGetErrorString(e));
     long long chunks = R / 64;
     if (chunks < 1) chunks = 1;
     if (chunks > 128) chunks = 128;

@@ -29,7 +29,13 @@ struct AdamWChunk {
     float grad_scale;   // gradients are multiplied by this first (1 = none)
 };
 
-__global__ __launch_bounds__(256) void adamw_kernel(AdamWChunk c) {
+__global__ __launch_bounds__(256) void adamw_kernel(AdamWChunk c, const float* __restrict__ dev_hyper) {
+    // step-dependent factors from device memory when given: a captured graph replays fixed kernel arguments
+    if (dev_hyper) {
+        c.lr_wd_keep = dev_hyper[0];
+        c.step_size = dev_hyper[1];
+        c.inv_sqrt_bc2 = dev_hyper[2];
+    }
     // wave-uniform scan: which tensor does this block belong to
     int t = 0;
     while (t + 1 < c.count && (int)blockIdx.x >= c.first_block[t + 1]) ++t;
@@ -73,10 +79,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamWChunk c) {
 
 // params/grads/exp_avg/exp_avg_sq: HOST arrays of n_tensors DEVICE pointers (fp32, contiguous); sizes: host array of
 // element counts. step is the 1-based step number of this update.
+// dev_hyper (nullable): 3 floats in DEVICE memory {1 - lr*weight_decay, lr/(1 - beta1^step), 1/sqrt(1 - beta2^step)}
+// read at run time in place of the values derived from lr/weight_decay/step, for launches replayed from a HIP graph
+// (the caller rewrites them before each replay, e.g. with mia_set_words).
 extern "C" int mia_adamw_step(int n_tensors, const void* const* params, const void* const* grads,
                               const void* const* exp_avg, const void* const* exp_avg_sq, const long long* sizes,
                               double lr, double beta1, double beta2, double eps, double weight_decay, int step,
-                              double grad_scale, void* stream) {
+                              double grad_scale, const float* dev_hyper, void* stream) {
     MIA_CHECK_ARG(n_tensors >= 0 && (n_tensors == 0 || (params && grads && exp_avg && exp_avg_sq && sizes)),
                   "mia_adamw_step: null table");
     MIA_CHECK_ARG(step >= 1, "mia_adamw_step: step must be >= 1 (got %d)", step);
@@ -112,8 +121,33 @@ extern "C" int mia_adamw_step(int n_tensors, const void* const* params, const vo
         }
         if (c.count == 0) continue;
         c.first_block[c.count] = blocks;
-        hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, s, c);
+        hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, s, c, dev_hyper);
         MIA_CHECK_LAUNCH("mia_adamw_step");
     }
+    return 0;
+}
+
+// ---- small by-value upload: n 32-bit words travel in the kernel arguments and are stored to dst by one wave.
+// Unlike an asynchronous copy from host memory, the values are fixed when the call returns, so the caller may
+// overwrite its buffer at once; used to refresh the per-step words a replayed graph reads (seed offset, dev_hyper).
+#define MIA_SET_WORDS_MAX 64
+struct WordPack {
+    unsigned w[MIA_SET_WORDS_MAX];
+};
+
+__global__ __launch_bounds__(64) void set_words_kernel(unsigned* __restrict__ dst, int n, WordPack v) {
+    const int i = threadIdx.x;
+    if (i < n) dst[i] = v.w[i];
+}
+
+extern "C" int mia_set_words(void* dst, int n, const unsigned* host_words, void* stream) {
+    MIA_CHECK_ARG(n >= 0 && n <= MIA_SET_WORDS_MAX, "mia_set_words: n must be 0..%d (got %d)", MIA_SET_WORDS_MAX, n);
+    if (n == 0) return 0;
+    MIA_CHECK_ARG(dst && host_words, "mia_set_words: null pointer");
+    WordPack v;
+    for (int i = 0; i < MIA_SET_WORDS_MAX; ++i) v.w[i] = i < n ? host_words[i] : 0u;
+    hipLaunchKernelGGL(set_words_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), (unsigned*)dst, n,
+                       v);
+    MIA_CHECK_LAUNCH("mia_set_words");
     return 0;
 }

@@ -292,8 +292,8 @@ extern "C" int mia_zero_slice_filter(const void* vol, int elem_bytes, int is_flo
     MIA_CHECK_ARG((elem_bytes == 1 || elem_bytes == 2 || elem_bytes == 4) && (!is_float || elem_bytes == 4),
                   "mia_zero_slice_filter: unsupported element type (%d bytes, float=%d)", elem_bytes, is_float);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(flags_ws, 0, (size_t)n_slices * sizeof(int), s);
-    MIA_CHECK_ARG(e == hipSuccess, "mia_zero_slice_filter: memset failed: %s", hipGetErrorString(e));
+    hipError_t e = mia_zero_words(flags_ws, n_slices, s);
+    MIA_CHECK_ARG(e == hipSuccess, "mia_zero_slice_filter: zero fill failed: %s", hipGetErrorString(e));
     const long long slice_bytes = slice_elems * elem_bytes;
     long long splits = slice_bytes / (16 * 256 * 8);  // >= 8 vector loads per thread
     if (splits < 1) splits = 1;

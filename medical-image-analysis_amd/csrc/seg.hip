@@ -375,7 +375,9 @@ extern "C" int mia_pixel_linear_bwd(int dtype, const void* x, const float* dlogi
 // ------------------------------------------------------------------------------------------------
 // channel dropout (Dropout2d): one keep/scale factor per (image, channel), from a counter-based hash
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void channel_dropout_mask_kernel(float* mask, int n, float p, unsigned long long seed) {
+__global__ __launch_bounds__(256) void channel_dropout_mask_kernel(float* mask, int n, float p, unsigned long long seed,
+                                                                   const unsigned long long* seed_off) {
+    if (seed_off) seed += seed_off[0] * 0x9E3779B97F4A7C15ull;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     unsigned long long z = (unsigned long long)i + seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
@@ -386,10 +388,11 @@ __global__ __launch_bounds__(256) void channel_dropout_mask_kernel(float* mask, 
     mask[i] = u >= p ? 1.0f / (1.0f - p) : 0.f;
 }
 
-extern "C" int mia_channel_dropout_mask(float* mask, int B, int C, float p, unsigned long long seed, void* stream) {
+extern "C" int mia_channel_dropout_mask(float* mask, int B, int C, float p, unsigned long long seed,
+                                        const unsigned long long* seed_offset, void* stream) {
     MIA_CHECK_ARG(mask && B > 0 && C > 0 && p >= 0.f && p < 1.f, "mia_channel_dropout_mask: bad arguments");
     hipLaunchKernelGGL(channel_dropout_mask_kernel, dim3(cdiv((long long)B * C, 256)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), mask, B * C, p, seed);
+                       reinterpret_cast<hipStream_t>(stream), mask, B * C, p, seed, seed_offset);
     MIA_CHECK_LAUNCH("mia_channel_dropout_mask");
     return 0;
 }

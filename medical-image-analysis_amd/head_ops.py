@@ -105,7 +105,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.act == ACT_RELU:
             # ReLU mask (fp32 MLP only; a residual is never combined with ReLU in this model)
             dy = dy.float().clone()
-            lib().mia_dropout_f32(_p(dy), _p(y.float()), dy.numel(), 0.0, 0, _stream())
+            lib().mia_dropout_f32(_p(dy), _p(y.float()), dy.numel(), 0.0, 0, None, _stream())
             dy = dy.to(x.dtype)
         N, K = weight.shape
         vec = 8 if x.dtype == torch.bfloat16 else 4
@@ -133,18 +133,19 @@ class AttentionFn(torch.autograd.Function):
         qkv = qkv.contiguous()
         P = torch.empty((B, heads, HW, HW), dtype=torch.float32, device=qkv.device)
         out = torch.empty((B * HW, C), dtype=qkv.dtype, device=qkv.device)
-        lib().mia_attention_fwd(_DT[qkv.dtype], _p(qkv), B, HW, C, heads, float(pdrop), seed, _p(P), _p(out), _stream())
-        ctx.meta = (B, HW, C, heads, float(pdrop), seed)
+        lib().mia_attention_fwd(_DT[qkv.dtype], _p(qkv), B, HW, C, heads, float(pdrop), seed, ops.seed_offset(), _p(P),
+                                _p(out), _stream())
+        ctx.meta = (B, HW, C, heads, float(pdrop), seed, ops.seed_offset())
         ctx.save_for_backward(qkv, P, out)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, P, out = ctx.saved_tensors
-        B, HW, C, heads, pdrop, seed = ctx.meta
+        B, HW, C, heads, pdrop, seed, soff = ctx.meta
         dqkv = torch.empty_like(qkv)
         lib().mia_attention_bwd(_DT[qkv.dtype], _p(qkv), _p(P), _p(dout.contiguous()), _p(out), B, HW, C, heads, pdrop,
-                                seed, _p(dqkv), _stream())
+                                seed, soff, _p(dqkv), _stream())
         return dqkv, None, None, None, None, None, None
 
 
@@ -159,20 +160,20 @@ class PoolNormFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=x.device)
         out, xhat, rstd = torch.empty((B, C), **f32), torch.empty((B, C), **f32), torch.empty((B,), **f32)
         lib().mia_pool_ln_dropout_fwd(_p(part), B, part.shape[1], H * W, C, _p(gamma), _p(beta), float(eps),
-                                      float(pdrop), seed, _p(out), _p(xhat), _p(rstd), _stream())
-        ctx.meta = (B, H, W, C, float(pdrop), seed, x.dtype)
+                                      float(pdrop), seed, ops.seed_offset(), _p(out), _p(xhat), _p(rstd), _stream())
+        ctx.meta = (B, H, W, C, float(pdrop), seed, x.dtype, ops.seed_offset())
         ctx.save_for_backward(gamma, xhat, rstd)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         gamma, xhat, rstd = ctx.saved_tensors
-        B, H, W, C, pdrop, seed, dt = ctx.meta
+        B, H, W, C, pdrop, seed, dt, soff = ctx.meta
         f32 = dict(dtype=torch.float32, device=dout.device)
         dpooled = torch.empty((B, C), **f32)
         dg_rows = torch.empty((B, C), **f32) if gamma is not None else None
         db_rows = torch.empty((B, C), **f32) if gamma is not None else None
-        lib().mia_pool_ln_dropout_bwd(_p(dout.contiguous()), B, C, _p(gamma), _p(xhat), _p(rstd), pdrop, seed,
+        lib().mia_pool_ln_dropout_bwd(_p(dout.contiguous()), B, C, _p(gamma), _p(xhat), _p(rstd), pdrop, seed, soff,
                                       _p(dpooled), _p(dg_rows), _p(db_rows), _stream())
         dx = torch.empty((B, H, W, C), dtype=dt, device=dout.device)
         lib().mia_broadcast_rows(_DT[dt], _p(dpooled), B, H * W, C, 1.0 / (H * W), None, _p(dx), _stream())
@@ -185,14 +186,14 @@ class DropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pdrop, seed):
         y = x.clone()
-        lib().mia_dropout_f32(_p(y), None, y.numel(), float(pdrop), seed, _stream())
-        ctx.meta = (float(pdrop), seed)
+        lib().mia_dropout_f32(_p(y), None, y.numel(), float(pdrop), seed, ops.seed_offset(), _stream())
+        ctx.meta = (float(pdrop), seed, ops.seed_offset())
         return y
 
     @staticmethod
     def backward(ctx, dy):
         g = dy.clone()
-        lib().mia_dropout_f32(_p(g), None, g.numel(), ctx.meta[0], ctx.meta[1], _stream())
+        lib().mia_dropout_f32(_p(g), None, g.numel(), ctx.meta[0], ctx.meta[1], ctx.meta[2], _stream())
         return g, None, None
 
 

@@ -39,6 +39,18 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class Replay:
+    """State of a HIP-graph capture of a training step. A replayed graph repeats its kernel arguments, so the two
+    things that change from step to step come from device memory instead: the dropout seeds get a per-replay offset
+    (`seed_off`, the address of a uint64 counter, None outside a capture) and AdamW reads its step-dependent factors
+    from a float table. graphs.GraphedTrainStep sets these around its capture and rewrites the memory per replay."""
+    seed_off = None
+
+
+def seed_offset():
+    return Replay.seed_off
+
+
 def _require_cuda(t: torch.Tensor):
     if not t.is_cuda:
         raise RuntimeError("mia_amd kernels need tensors on an MI355X device; there is no CPU path")
@@ -111,6 +123,12 @@ class ZeroPool:
     once the gradients cut from it are gone. Chunks are tied to the (device, stream) they were filled on."""
     CHUNK = 16 << 20   # floats
     _chunks = {}       # (device index, stream id) -> [tensor, offset]
+
+    @classmethod
+    def drop(cls):
+        """Forget the partly used chunks. Around a graph capture: slices cut during the capture must come from a
+        chunk whose fill is itself part of the graph, and none of the graph's memory may be handed out afterwards."""
+        cls._chunks.clear()
 
     @classmethod
     def take(cls, rows: int, cols: int, device) -> torch.Tensor:

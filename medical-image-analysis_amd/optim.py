@@ -4,6 +4,7 @@ Same constructor arguments, param_groups and state-dict layout (step / exp_avg /
 which the reference builds at train.py:193-197 and finetune.py:232-248, so LR schedulers
 (ReduceLROnPlateau, train.py:199-201) and optimizer checkpoints (train.py:440) keep working."""
 import ctypes
+import math
 
 import torch
 
@@ -21,6 +22,39 @@ class AdamW(torch.optim.Optimizer):
         # step (several hundred tiny host ops); here the parameters that share a count share ONE state["step"] tensor,
         # made once per step
         self._pstep = {}
+        # set while graphs.GraphedTrainStep captures step(): (address of a device float table, list of launches);
+        # each captured launch reads its step-dependent factors from one 4-float row of the table
+        self._capture = None
+
+    @staticmethod
+    def step_factors(lr, b1, b2, weight_decay, k):
+        """The three step-dependent factors of update k, formed in double as mia_adamw_step forms them."""
+        return 1.0 - lr * weight_decay, lr / (1.0 - b1 ** k), 1.0 / math.sqrt(1.0 - b2 ** k)
+
+    def begin_capture(self, table_ptr: int, max_rows: int):
+        self._capture = (table_ptr, max_rows, [])
+
+    def end_capture(self):
+        """-> [(group index, [params])], one entry per table row, in the order the launches were captured."""
+        rows = self._capture[2]
+        self._capture = None
+        return rows
+
+    def advance_captured(self, rows):
+        """Host-side bookkeeping of one replayed step: bumps the step counts of the captured launches and returns the
+        table contents (4 floats per row) for that step at the groups' CURRENT learning rates."""
+        out = []
+        for gi, plist in rows:
+            group = self.param_groups[gi]
+            k = self._pstep[plist[0]] + 1
+            shared = torch.tensor(float(k))
+            for p in plist:
+                self._pstep[p] = k
+                self.state[p]["step"] = shared
+            b1, b2 = group["betas"]
+            out.extend(self.step_factors(float(group["lr"]), float(b1), float(b2), float(group["weight_decay"]), k))
+            out.append(0.0)
+        return out
 
     def _table(self, gi, ps):
         """ctypes pointer tables of one group, rebuilt only when the set of (param, grad) storages changes."""
@@ -74,8 +108,18 @@ class AdamW(torch.optim.Optimizer):
                 for p in plist:
                     self.state[p]["step"] = shared
                 n, tp, tg, tm, tv, sizes = self._table((gi, si), plist)
+                dev_hyper = None
+                if self._capture is not None:
+                    ptr, max_rows, rows = self._capture
+                    if len(rows) >= max_rows:
+                        raise RuntimeError("too many distinct (group, step count) launches for one captured step")
+                    if grad_scale != 1.0:
+                        raise RuntimeError("grad_scale cannot be captured")
+                    dev_hyper = ptr + 16 * len(rows)
+                    rows.append((gi, plist))
                 lib().mia_adamw_step(n, tp, tg, tm, tv, sizes, float(group["lr"]), float(b1), float(b2),
-                                     float(group["eps"]), float(group["weight_decay"]), k, float(grad_scale), _stream())
+                                     float(group["eps"]), float(group["weight_decay"]), k, float(grad_scale), dev_hyper,
+                                     _stream())
         return loss
 
     def load_state_dict(self, state_dict):

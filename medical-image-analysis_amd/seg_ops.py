@@ -56,7 +56,7 @@ class DecoderBlockFn(torch.autograd.Function):
         mask = None
         if cfg.training and cfg.pdrop > 0:
             mask = torch.empty((B, Co), dtype=torch.float32, device=x.device)
-            lib().mia_channel_dropout_mask(_p(mask), B, Co, float(cfg.pdrop), _seed(), _stream())
+            lib().mia_channel_dropout_mask(_p(mask), B, Co, float(cfg.pdrop), _seed(), ops.seed_offset(), _stream())
         col2 = im2col3x3(y1.view(B, H, W, Co), scale=st1[0], shift=st1[1], act=ACT_RELU, gate=mask)
         w2m, w2mT = _conv_weight_matrix(w2, dt, need_bwd)
         y2, part = ops.gemm_nt(col2, w2m, stats_rows=rows)

@@ -25,3 +25,36 @@ for batch in (1, 8, 32, 128):
         res[name] = (time.perf_counter() - t0) / 20 * 1e3
     print(f"batch {batch:4d} 300x300 bf16 eval forward: eager {res['eager']:7.2f} ms  graph {res['graph']:7.2f} ms  "
           f"({batch / res['graph'] * 1e3:8.0f} images/s)", flush=True)
+
+# ---- whole training step (forward, cross-entropy, backward, AdamW), eager launches against one graph replay
+from mia_amd.graphs import GraphedTrainStep
+from mia_amd.head_ops import CrossEntropyLoss
+from mia_amd.optim import AdamW
+
+model.train()
+crit = CrossEntropyLoss()
+opt = AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
+for batch in (8, 16, 32, 64):
+    x = torch.randn(batch, 3, 300, 300, device="cuda")
+    y = torch.randint(0, 4, (batch,), device="cuda")
+
+    def eager():
+        opt.zero_grad(set_to_none=True)
+        loss = crit(model(x, "classification", "d"), y)
+        loss.backward()
+        opt.step()
+
+    step = GraphedTrainStep(model, "classification", "d", crit, opt, x, y)
+    res = {}
+    for name, fn in (("eager", eager), ("graph", lambda: step(x, y, copy_out=False))):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        res[name] = (time.perf_counter() - t0) / 20 * 1e3
+    print(f"batch {batch:4d} 300x300 bf16 train step: eager {res['eager']:7.2f} ms  graph {res['graph']:7.2f} ms  "
+          f"({batch / res['graph'] * 1e3:8.0f} images/s)", flush=True)
+    del step

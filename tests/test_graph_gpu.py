@@ -37,3 +37,115 @@ def test_graph_needs_eval_mode():
     model = FoundationModel(backbone="efficientnet_b3", pretrained=False, classification_heads={"d": 2}).cuda().train()
     with pytest.raises(RuntimeError, match="eval"):
         GraphedForward(model, "classification", "d", torch.randn(1, 3, 64, 64, device="cuda"))
+
+
+# ------------------------------------------------------------------------------------------------
+# whole training step (forward, loss, backward, AdamW) as one replay
+# ------------------------------------------------------------------------------------------------
+import copy  # noqa: E402
+
+from mia_amd.graphs import GraphedTrainStep  # noqa: E402
+from mia_amd.head_ops import CrossEntropyLoss  # noqa: E402
+from mia_amd.optim import AdamW  # noqa: E402
+
+
+def _set_dropout(model, p):
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
+            m.p = p
+
+
+def _cls_model(dtype, dropout):
+    torch.manual_seed(0)
+    model = FoundationModel(backbone="efficientnet_b3", pretrained=False, dropout=dropout,
+                            classification_heads={"d": 4}, use_attention=True, compute_dtype=dtype).cuda().train()
+    _set_dropout(model, dropout)
+    return model
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_graphed_train_step_follows_eager(dtype):
+    """Without dropout a graphed run and an eager run from the same start stay together (the weight-gradient GEMMs
+    accumulate with float atomics, so two eager runs already differ in the last bits): per-step losses within 2e-3
+    relative, the mean parameter difference after 5 steps a small fraction of the mean parameter movement, and the
+    learning-rate change made between steps, the optimizer's step counts and the BatchNorm buffers all follow."""
+    eager = _cls_model(dtype, 0.0)
+    graphed = copy.deepcopy(eager)
+    start = [p.detach().clone() for p in graphed.parameters()]
+    crit = CrossEntropyLoss()
+    opt_e = AdamW(eager.parameters(), lr=1e-3, weight_decay=1e-4)
+    opt_g = AdamW(graphed.parameters(), lr=1e-3, weight_decay=1e-4)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    batches = [(torch.randn(4, 3, 96, 96, device="cuda", generator=g),
+                torch.randint(0, 4, (4,), device="cuda", generator=g)) for _ in range(5)]
+    step = GraphedTrainStep(graphed, "classification", "d", crit, opt_g, *batches[0])
+    # construction leaves training where it was
+    for p, s0 in zip(graphed.parameters(), start):
+        assert torch.equal(p, s0)
+    for (n1, b1), (n2, b2) in zip(eager.named_buffers(), graphed.named_buffers()):
+        assert torch.equal(b1, b2), n1
+    assert all(int(opt_g.state[p]["step"]) == 0 for p in graphed.parameters() if p in opt_g.state)
+
+    for i, (x, y) in enumerate(batches):
+        if i == 3:
+            opt_e.param_groups[0]["lr"] = opt_g.param_groups[0]["lr"] = 2.5e-4
+        opt_e.zero_grad(set_to_none=True)
+        le = crit(eager(x, "classification", "d"), y)
+        le.backward()
+        opt_e.step()
+        lg = step(x, y)
+        tol = 2e-3 if dtype == "fp32" else 5e-2
+        le, lg = float(le.detach()), float(lg.detach())
+        assert abs(le - lg) <= tol * abs(le), (i, le, lg)
+    moved = max(float((p - s0).abs().max()) for p, s0 in zip(eager.parameters(), start))
+    assert moved > 1e-3
+    # (Adam's normalised update turns last-bit gradient differences of near-zero gradients into full-size steps, so
+    # single parameters may differ by a sizeable fraction of the largest update; the mean difference must be small)
+    mean_diff = sum(float((pe - pg).abs().sum()) for pe, pg in zip(eager.parameters(), graphed.parameters())) / \
+        sum(p.numel() for p in eager.parameters())
+    mean_move = sum(float((p - s0).abs().sum()) for p, s0 in zip(eager.parameters(), start)) / \
+        sum(p.numel() for p in eager.parameters())
+    assert mean_diff <= (0.05 if dtype == "fp32" else 0.5) * mean_move, (mean_diff, mean_move)
+    for p in graphed.parameters():
+        if p in opt_g.state:
+            assert int(opt_g.state[p]["step"]) == 5
+    for (n1, b1), (n2, b2) in zip(eager.named_buffers(), graphed.named_buffers()):
+        if n1.endswith("num_batches_tracked"):
+            assert torch.equal(b1, b2), n1
+        else:
+            assert torch.allclose(b1.float(), b2.float(), rtol=2e-2, atol=2e-3), n1
+
+
+def test_graphed_train_step_draws_new_dropout_masks():
+    """lr = 0 freezes the weights, so the loss of a repeated batch changes only through the dropout masks: replays
+    must differ from each other, and the sequence must repeat under torch.manual_seed."""
+    model = _cls_model("bf16", 0.5)
+    crit = CrossEntropyLoss()
+    opt = AdamW(model.parameters(), lr=0.0, weight_decay=0.0)
+    x = torch.randn(4, 3, 96, 96, device="cuda")
+    y = torch.tensor([0, 1, 2, 3], device="cuda")
+    step = GraphedTrainStep(model, "classification", "d", crit, opt, x, y)
+    torch.manual_seed(7)
+    a = [float(step(x, y)) for _ in range(4)]
+    torch.manual_seed(7)
+    b = [float(step(x, y)) for _ in range(4)]
+    assert len(set(a)) == 4, a
+    assert a == b, (a, b)
+
+
+def test_graphed_train_step_refusals():
+    model = _cls_model("bf16", 0.1)
+    crit = CrossEntropyLoss()
+    x, y = torch.randn(2, 3, 64, 64, device="cuda"), torch.tensor([0, 1], device="cuda")
+    with pytest.raises(TypeError):
+        GraphedTrainStep(model, "classification", "d", crit, torch.optim.AdamW(model.parameters()), x, y)
+    opt = AdamW(model.parameters(), lr=1e-3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        GraphedTrainStep(model, "classification", "d", crit, opt, x.cpu(), y.cpu())
+    model.eval()
+    with pytest.raises(RuntimeError, match="train"):
+        GraphedTrainStep(model, "classification", "d", crit, opt, x, y)
+    model.train()
+    step = GraphedTrainStep(model, "classification", "d", crit, opt, x, y)
+    with pytest.raises(ValueError):
+        step(torch.randn(3, 3, 64, 64, device="cuda"), torch.tensor([0, 1, 2], device="cuda"))

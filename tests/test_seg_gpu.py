@@ -98,7 +98,7 @@ def test_channel_dropout_mask_keeps_whole_channels():
     x = nhwc(randn(13, 4, 8, 6, 6)).cuda()
     torch.manual_seed(5)
     mask = torch.empty((64, 256), device="cuda")
-    mia_amd.lib().mia_channel_dropout_mask(mask.data_ptr(), 64, 256, 0.5, 1234, None)
+    mia_amd.lib().mia_channel_dropout_mask(mask.data_ptr(), 64, 256, 0.5, 1234, None, None)
     vals = set(mask.unique().tolist())
     assert vals == {0.0, 2.0}
     assert abs(mask.eq(0).float().mean().item() - 0.5) < 0.03
