@@ -13,6 +13,7 @@
 //                     both with the fused epilogue g = dA * silu'(z), partials sum(g), sum(g*xhat)
 //   dwconv_bwd_weight dW[c][kh][kw] = sum dY * pro(x)     (per-workgroup partial slab + ordered reduce)
 #include "common.h"
+#include <stdlib.h>
 
 #define DW_PW 4  // output pixels per patch row
 
@@ -305,6 +306,165 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
         }
     }
     if (p.stats) dw_write_stats(p, red, tid, nvec, npt, c0, cbv, st_s, st_q);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 depthwise convolution on the matrix cores (forward, and the stride-1 data gradient with flipped taps).
+// A depthwise tap is a product with a DIAGONAL matrix: for 16 channels and 16 pixels,
+//   D[ch][pix] += diag(w_tap)[ch][ch'] * X_tap[ch'][pix],   X_tap = the staged input shifted by the tap.
+// One v_mfma_f32_16x16x16 per tap does that for 256 outputs; 15/16 of its multiplies hit zeros, but the matrix pipe
+// has the headroom (a whole 5x5 layer is ~10 us of MFMA time) and the vector ALU is left with staging and the
+// epilogue only, which is what bounded the per-thread-patch kernel above.
+// Operand layouts make this elementwise from the lane's point of view: lane (pix = lane%16, quad = lane/16) supplies
+// channels 4*quad..+3 of pixel `pix` as the B operand -- one 8-byte LDS read at a per-lane base plus a per-tap
+// offset -- and receives the four outputs of exactly those channels at that pixel. The diagonal weights are the A
+// operand, fixed for the kernel: wave w of the workgroup owns channels 16w..16w+15 of the 64-channel block.
+// Any 16 output pixels of the tile form a group (linear index over the tile), so odd map sizes waste no MFMA rows.
+// The LDS pixel stride is padded to 136 bytes: the 32 lanes of a half-wave then cover every bank pair exactly twice.
+// Staging (register prefetch of the next tile, BatchNorm+SiLU on the way into LDS) is shared with the kernel above.
+// Weights are rounded to bf16 here (the per-thread-patch kernel multiplies by the fp32 masters).
+typedef __attribute__((ext_vector_type(4))) float dw_f32x4;
+typedef __attribute__((ext_vector_type(4))) short dw_s16x4;
+// Channels per workgroup: 64 (wave w owns channel group w) or 32 (waves w and w+2 share channel group w%2 and take
+// alternate pixel groups). The narrower block halves the LDS per staged pixel, so that twice as large a window fits:
+// whole 19x19 maps with their 5x5 halo instead of four 10x10 quarters that stage every pixel 2.2 times.
+constexpr int DWM_NV = 17;    // staged pixels per thread
+
+template <int K, int S, int DWM_CB>
+__global__ __launch_bounds__(256) void dwconv_mfma_kernel(DwParams p) {
+    typedef bf16_t T;
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int DWM_CBP = DWM_CB + 4;   // LDS pixel stride in elements
+    constexpr int NG = DWM_CB / 16;       // channel groups
+    constexpr int WPG = 4 / NG;           // waves per channel group
+    constexpr int nvec = DWM_CB / 4, npt = 256 / nvec;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int TH = p.TH, TW = p.TW;
+    const int IHT = (TH - 1) * S + K, IWT = (TW - 1) * S + K;
+    float* red = reinterpret_cast<float*>(smem);     // [256][8]
+    T* tile = reinterpret_cast<T*>(red + 256 * 8);   // [IHT*IWT][DWM_CBP]
+
+    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = blockIdx.y * DWM_CB;
+    const int cbv = (p.C - c0) < DWM_CB ? (p.C - c0) : DWM_CB;
+    // staging role: thread (pt, cv) moves the 4-channel vector cv of pixels pt, pt+npt, ...
+    const int cv = tid % nvec, pt = tid / nvec;
+    const int cst = c0 + cv * 4;
+    const bool st_ok = cv * 4 < cbv;
+    // compute role
+    const int pix_l = lane & 15, quad = lane >> 4;
+    const int grp = wave % NG, sub = wave / NG;
+    const int cl = grp * 16 + quad * 4;
+    const int c = c0 + cl;
+    const bool cvalid = cl < cbv;
+    const bool wave_on = grp * 16 < cbv;
+    const bool has_pro = p.pscale != nullptr;
+
+    const f22 zero22 = {v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+    f22 st_s = zero22, st_q = zero22;
+    const int tiles_per_img = p.tiles_h * p.tiles_w;
+    const int total = p.B * tiles_per_img;
+    const int npos = TH * TW;
+
+    TileRegs<T, DWM_NV> regs;
+    auto fetch = [&](int work) {
+        const int b = work / tiles_per_img;
+        const int tr = work - b * tiles_per_img;
+        const int trh = tr / p.tiles_w;
+        const int oh0 = trh * TH, ow0 = (tr - trh * p.tiles_w) * TW;
+        dw_tile_fetch<T, DWM_NV>(regs, x + (size_t)b * p.H * p.W * p.C, IHT, IWT, oh0 * S - PAD, ow0 * S - PAD, p.H,
+                                 p.W, p.C, cst, st_ok, pt, npt);
+    };
+    const TileWalk walk = make_tile_walk(total);
+    if (walk.first < walk.count) fetch(walk.base + walk.first);
+    // constants are loaded AFTER the first tile's loads are issued: one memory latency for both
+    dw_s16x4 wA[K * K];
+    {
+        const int ch = grp * 16 + pix_l;   // channel of the A row this lane holds
+        const bool mine = (pix_l >> 2) == quad && ch < cbv;
+        const int j = pix_l & 3;
+#pragma unroll
+        for (int t = 0; t < K * K; ++t) {
+            const int ts = p.flip ? (K * K - 1 - t) : t;
+            const short wv = mine ? (short)f32_to_bf16_bits(p.w[(size_t)(c0 + ch) * (K * K) + ts]) : (short)0;
+            wA[t] = dw_s16x4{j == 0 ? wv : (short)0, j == 1 ? wv : (short)0, j == 2 ? wv : (short)0,
+                             j == 3 ? wv : (short)0};
+        }
+    }
+    f22 psc = {v2f{1.f, 1.f}, v2f{1.f, 1.f}}, psh = zero22;
+    if (has_pro && st_ok) { psc = load22<float>(p.pscale + cst); psh = load22<float>(p.pshift + cst); }
+    f22 es = zero22, eh = zero22, em = zero22, er = zero22;
+    if (p.yfwd && cvalid) {
+        es = load22<float>(p.escale + c); eh = load22<float>(p.eshift + c);
+        em = load22<float>(p.emean + c); er = load22<float>(p.erstd + c);
+    }
+    for (int wi = walk.first; wi < walk.count; wi += walk.stride) {
+        const int work = walk.base + wi;
+        const int b = work / tiles_per_img;
+        const int tr = work - b * tiles_per_img;
+        const int trh = tr / p.tiles_w;
+        const int oh0 = trh * TH, ow0 = (tr - trh * p.tiles_w) * TW;
+        __syncthreads();  // previous tile fully consumed
+        dw_tile_commit<T, DWM_NV>(regs, tile, IHT * IWT, cv, pt, npt, DWM_CBP, has_pro, psc, psh);
+        __syncthreads();
+        if (wi + walk.stride < walk.count) fetch(work + walk.stride);  // in flight while this tile is computed
+        if (wave_on) {
+            for (int g0 = sub * 16; g0 < npos; g0 += 16 * WPG) {
+                int q = g0 + pix_l;
+                const bool qv = q < npos;
+                if (!qv) q = 0;
+                const int ohl = q / TW, owl = q - ohl * TW;
+                const T* bp = tile + (unsigned)(((ohl * S) * IWT + owl * S) * DWM_CBP + cl);
+                dw_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                // one tap row of B operands ahead of the MFMAs that consume it, so the LDS latency is paid once per
+                // pixel group and not once per row
+                dw_s16x4 cur[K], nxt[K];
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) cur[kw] = *reinterpret_cast<const dw_s16x4*>(bp + kw * DWM_CBP);
+#pragma unroll
+                for (int kh = 0; kh < K; ++kh) {
+                    if (kh + 1 < K) {
+                        const T* rp = bp + (unsigned)((kh + 1) * IWT * DWM_CBP);
+#pragma unroll
+                        for (int kw = 0; kw < K; ++kw) nxt[kw] = *reinterpret_cast<const dw_s16x4*>(rp + kw * DWM_CBP);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // keep the loads above the MFMAs (the scheduler sinks them)
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wA[kh * K + kw], cur[kw], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw) cur[kw] = nxt[kw];
+                }
+                const int oh = oh0 + ohl, ow = ow0 + owl;
+                if (qv && cvalid && oh < p.OH && ow < p.OW) {
+                    const unsigned idx = (unsigned)(((b * p.OH + oh) * p.OW + ow) * p.C + c);
+                    const f22 v = {v2f{acc[0], acc[1]}, v2f{acc[2], acc[3]}};
+                    dw_epilogue_store<T>(p, idx, v, es, eh, em, er, st_s, st_q);
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        __syncthreads();
+        red[tid * 8 + 0] = st_s.lo.x; red[tid * 8 + 1] = st_s.lo.y; red[tid * 8 + 2] = st_s.hi.x; red[tid * 8 + 3] = st_s.hi.y;
+        red[tid * 8 + 4] = st_q.lo.x; red[tid * 8 + 5] = st_q.lo.y; red[tid * 8 + 6] = st_q.hi.x; red[tid * 8 + 7] = st_q.hi.y;
+        __syncthreads();
+        if (tid < cbv) {   // channel c0 + tid: group tid/16, quad (tid%16)/4, element tid%4; sum over its lanes
+            const int e = tid & 3;
+            float a = 0.f, bsum = 0.f;
+            for (int sb = 0; sb < WPG; ++sb) {
+                const int src = (sb * NG + (tid >> 4)) * 64 + ((tid >> 2) & 3) * 16;
+                for (int pl = 0; pl < 16; ++pl) {
+                    a += red[(src + pl) * 8 + e];
+                    bsum += red[(src + pl) * 8 + 4 + e];
+                }
+            }
+            p.stats[((size_t)blockIdx.x * 2 + 0) * p.C + c0 + tid] = a;
+            p.stats[((size_t)blockIdx.x * 2 + 1) * p.C + c0 + tid] = bsum;
+        }
+    }
 }
 
 // Stride-2 data gradient on LDS tiles. A "cell" is one dY position (r, c); it owns the 2x2 block of dA pixels
@@ -615,6 +775,91 @@ static int dispatch_tile(const DwParams& p, int K, int S, int grid_x, hipStream_
 }
 static int tile_ph(int S) { return S == 1 ? 2 : 1; }
 
+// Output tile for the matrix-core kernel: any TH x TW whose halo window fits the per-thread staging registers and the
+// LDS budget; scored by halo overhead, wasted output slots and how well TH*TW fills groups of 16 pixels.
+static double pick_tile_mfma(int OH, int OW, int K, int S, int cb, int lds_budget, int* th, int* tw) {
+    const int max_px = (256 / (cb / 4)) * DWM_NV;
+    double best = -1.0;
+    *th = 1; *tw = 1;
+    for (int a = 1; a <= 32 && a <= OH + 3; ++a)
+        for (int b = 1; b <= 32 && b <= OW + 3; ++b) {
+            const int iht = (a - 1) * S + K, iwt = (b - 1) * S + K;
+            if (iht * iwt > max_px) continue;
+            if ((long long)iht * iwt * (cb + 4) * 2 > lds_budget) continue;
+            const int nth = cdiv(OH, a), ntw = cdiv(OW, b);
+            const double useful = (double)OH * OW;
+            const double staged = (double)nth * ntw * iht * iwt;
+            const double slots = (double)nth * ntw * a * b;
+            const double groups = (double)(a * b) / (double)(cdiv(a * b, 16) * 16);
+            const double score = (useful / staged) * (useful / slots) * groups;
+            if (score > best) { best = score; *th = a; *tw = b; }
+        }
+    return best;
+}
+
+// 64 channels per workgroup unless 32 stages markedly less halo (or wastes fewer channels of the last block).
+static int pick_cb_mfma(int OH, int OW, int C, int K, int S, int* th, int* tw) {
+    int th64, tw64, th32, tw32;
+    const double s64 = pick_tile_mfma(OH, OW, K, S, 64, 38 * 1024, &th64, &tw64) * C / (cdiv(C, 64) * 64.0);
+    const double s32 = pick_tile_mfma(OH, OW, K, S, 32, 38 * 1024, &th32, &tw32) * C / (cdiv(C, 32) * 32.0);
+    if (s32 > 1.15 * s64) { *th = th32; *tw = tw32; return 32; }
+    *th = th64; *tw = tw64;
+    return 64;
+}
+
+// Workgroups per channel block: about as many as the chip keeps resident (3 per CU at the 5x5 kernel's register
+// count, 4 for 3x3), each walking an equal number of tiles, so that the per-workgroup set-up is paid once and the next
+// tile's loads overlap the current tile's arithmetic.
+static int dw_mfma_grid(int total, int chan_blocks, int K) {
+    const int resident = 256 * (K == 5 ? 3 : 4);
+    int target = resident / chan_blocks;
+    if (target < 8) target = 8;
+    static const bool big = getenv("MIA_DW_GRID_BIG") != nullptr;   // A/B switch for benchmarking
+    if (big || K == 3) return total < 8192 ? total : 8192;
+    const int per_wg = cdiv(total, target);
+    return cdiv(total, per_wg);
+}
+
+// bf16 only. Measured at batch 128 against the per-thread-patch kernel: ahead on maps up to 38x38 (1.2-1.7x on the
+// 5x5 layers), behind on the 75x75 and 150x150 maps (streaming-bound there, and the 16-pixel staging tiles of this
+// kernel re-read more halo), on layers narrower than 64 channels and on small stride-2 maps that tile badly.
+static bool dw_use_mfma(int dtype, int C, int S, int OH, int OW) {
+    static const bool off = getenv("MIA_DW_NO_MFMA") != nullptr;   // A/B switch for benchmarking
+    return !off && dtype == MIA_BF16 && C % 4 == 0 && C >= 64 && OH * OW <= 1600 && !(S == 2 && OH * OW < 1024);
+}
+
+// p.x/p.y/p.H/p.W/p.OH/p.OW/flip/prologue/epilogue/stats set by the caller; fills the tile fields and launches.
+static int launch_mfma(DwParams& p, int K, int S, float* stats, int part_rows, hipStream_t s, int* gx_out) {
+    p.CB = pick_cb_mfma(p.OH, p.OW, p.C, K, S, &p.TH, &p.TW);
+    p.tiles_h = cdiv(p.OH, p.TH); p.tiles_w = cdiv(p.OW, p.TW);
+    const int total = p.B * p.tiles_h * p.tiles_w;
+    int gx = dw_mfma_grid(total, cdiv(p.C, p.CB), K);
+    if (stats && gx > part_rows) gx = part_rows;
+    *gx_out = gx;
+    const int IHT = (p.TH - 1) * S + K, IWT = (p.TW - 1) * S + K;
+    const size_t lds = 256 * 8 * 4 + (size_t)IHT * IWT * (p.CB + 4) * 2;
+    dim3 grid(gx, cdiv(p.C, p.CB));
+#define MIA_DWM(K_, S_) \
+    do { \
+        if (p.CB == 64) hipLaunchKernelGGL((dwconv_mfma_kernel<K_, S_, 64>), grid, dim3(256), lds, s, p); \
+        else hipLaunchKernelGGL((dwconv_mfma_kernel<K_, S_, 32>), grid, dim3(256), lds, s, p); \
+    } while (0)
+    if (K == 3 && S == 1) MIA_DWM(3, 1);
+    else if (K == 3 && S == 2) MIA_DWM(3, 2);
+    else if (K == 5 && S == 1) MIA_DWM(5, 1);
+    else if (K == 5 && S == 2) MIA_DWM(5, 2);
+    else return -1;
+#undef MIA_DWM
+    return 0;
+}
+
+// grid size launch_mfma will use (for clearing the statistics rows no workgroup owns)
+static int mfma_grid_for(const DwParams& p, int K, int S) {
+    int th, tw;
+    const int cb = pick_cb_mfma(p.OH, p.OW, p.C, K, S, &th, &tw);
+    return dw_mfma_grid(p.B * cdiv(p.OH, th) * cdiv(p.OW, tw), cdiv(p.C, cb), K);
+}
+
 static int dw_common_checks(const char* name, int dtype, int B, int H, int W, int C, int K, int S) {
     MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "%s: bad dtype %d", name, dtype);
     MIA_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "%s: bad shape B=%d H=%d W=%d C=%d (C%%4==0)", name,
@@ -635,13 +880,26 @@ extern "C" int mia_dwconv_fwd(int dtype, const void* x, int B, int H, int W, int
     const int pad = (K - 1) / 2;
     p.OH = (H + 2 * pad - K) / S + 1; p.OW = (W + 2 * pad - K) / S + 1;
     p.pscale = pscale; p.pshift = pshift; p.flip = 0; p.stats = stats;
+    MIA_CHECK_ARG(!stats || (part_rows > 0 && part_rows <= 65535), "mia_dwconv_fwd: stats needs 0 < part_rows <= 65535");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dw_use_mfma(dtype, C, S, p.OH, p.OW)) {
+        int gx = 0;
+        // rows no workgroup owns must still read as zero: the row count is known only after the tile is picked, so
+        // clear all of them first when the grid may be smaller
+        const int gxm = mfma_grid_for(p, K, S);
+        if (stats && gxm < part_rows) {
+            hipError_t e = mia_zero_words(stats + (size_t)gxm * 2 * C, (long long)(part_rows - gxm) * 2 * C, s);
+            MIA_CHECK_ARG(e == hipSuccess, "mia_dwconv_fwd: zero fill failed: %s", hipGetErrorString(e));
+        }
+        MIA_CHECK_ARG(launch_mfma(p, K, S, stats, part_rows, s, &gx) == 0, "mia_dwconv_fwd: no kernel for K=%d S=%d", K, S);
+        MIA_CHECK_LAUNCH("mia_dwconv_fwd");
+        return 0;
+    }
     p.CB = pick_cb(C);
     const int elem = dtype == MIA_BF16 ? 2 : 4;
     pick_tile(p.OH, p.OW, K, S, p.CB, elem, tile_ph(S), DW_NV, 0, dtype == MIA_BF16 ? 32768 : 65536, &p.TH, &p.TW);
     p.tiles_h = cdiv(p.OH, p.TH); p.tiles_w = cdiv(p.OW, p.TW);
     const int total = B * p.tiles_h * p.tiles_w;
-    MIA_CHECK_ARG(!stats || (part_rows > 0 && part_rows <= 65535), "mia_dwconv_fwd: stats needs 0 < part_rows <= 65535");
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int gx = total < 8192 ? total : 8192;
     if (stats) {
         if (gx > part_rows) gx = part_rows;
@@ -675,6 +933,17 @@ extern "C" int mia_dwconv_bwd_data(int dtype, const void* dy, int B, int H, int 
     if (S == 1) {
         // correlation with flipped taps: same tiling kernel, input = dY (OHxOW == HxW), output = dA
         p.x = dy; p.y = dx; p.H = OH; p.W = OW; p.OH = H; p.OW = W; p.flip = 1;
+        if (dw_use_mfma(dtype, C, 1, p.OH, p.OW)) {
+            const int gxm = mfma_grid_for(p, K, 1);
+            if (stats && gxm < part_rows) {
+                hipError_t e = mia_zero_words(stats + (size_t)gxm * 2 * C, (long long)(part_rows - gxm) * 2 * C, s);
+                MIA_CHECK_ARG(e == hipSuccess, "mia_dwconv_bwd_data: zero fill failed: %s", hipGetErrorString(e));
+            }
+            int gx = 0;
+            MIA_CHECK_ARG(launch_mfma(p, K, 1, stats, part_rows, s, &gx) == 0, "mia_dwconv_bwd_data: no kernel for K=%d", K);
+            MIA_CHECK_LAUNCH("mia_dwconv_bwd_data");
+            return 0;
+        }
         pick_tile(p.OH, p.OW, K, 1, p.CB, elem, tile_ph(1), DW_NV, 0, dtype == MIA_BF16 ? 32768 : 65536, &p.TH, &p.TW);
         p.tiles_h = cdiv(p.OH, p.TH); p.tiles_w = cdiv(p.OW, p.TW);
         const int total = B * p.tiles_h * p.tiles_w;

@@ -43,6 +43,9 @@ for mode in ("fwd", "bwdd", "bwdw"):
     CASES[f"dw{mode}_s2"] = (lambda m=mode: dw_case(38, 288, 5, 1, m))     # stage 2.x
     CASES[f"dw{mode}_s20"] = (lambda m=mode: dw_case(75, 192, 5, 2, m))    # stage 2.0
     CASES[f"dw{mode}_s30"] = (lambda m=mode: dw_case(38, 288, 3, 2, m))    # stage 3.0
+    CASES[f"dw{mode}_s3"] = (lambda m=mode: dw_case(19, 576, 3, 1, m))     # stage 3.x
+    CASES[f"dw{mode}_s6"] = (lambda m=mode: dw_case(10, 2304, 3, 1, m))    # stage 6.x
+    CASES[f"dw{mode}_s0"] = (lambda m=mode: dw_case(150, 40, 3, 1, m))     # stage 0.0
 
 def gemm_case(M, N, K, pro, stats, act=None, use_gate=True):
     a, b = rnd(M, K), rnd(N, K)
