@@ -341,8 +341,10 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(DwParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int TH = p.TH, TW = p.TW;
     const int IHT = (TH - 1) * S + K, IWT = (TW - 1) * S + K;
-    float* red = reinterpret_cast<float*>(smem);     // [256][8]
-    T* tile = reinterpret_cast<T*>(red + 256 * 8);   // [IHT*IWT][DWM_CBP]
+    const int npos = TH * TW, npos16 = (npos + 15) & ~15;
+    int4* ptab = reinterpret_cast<int4*>(smem);      // [npos16]: per output pixel of the tile, see below
+    T* tile = reinterpret_cast<T*>(ptab + npos16);   // [IHT*IWT][DWM_CBP]
+    float* red = reinterpret_cast<float*>(tile);     // [256][8], used after the last tile only
 
     const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -365,7 +367,14 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(DwParams p) {
     f22 st_s = zero22, st_q = zero22;
     const int tiles_per_img = p.tiles_h * p.tiles_w;
     const int total = p.B * tiles_per_img;
-    const int npos = TH * TW;
+    // The walk over a tile's output pixels is the same for every tile: tabulate, once, for the q-th pixel its byte
+    // offset in the staged window, its element offset in the output image relative to the tile's origin, and its
+    // (row, col) for the edge test. The pixel-group loop then costs one LDS read instead of a division per group.
+    for (int q = tid; q < npos16; q += 256) {
+        const int ohl = q / TW, owl = q - ohl * TW;
+        ptab[q] = q < npos ? make_int4(((ohl * S) * IWT + owl * S) * DWM_CBP * 2, (ohl * p.OW + owl) * p.C, ohl, owl)
+                           : make_int4(0, 0, 1 << 20, 1 << 20);
+    }
 
     TileRegs<T, DWM_NV> regs;
     auto fetch = [&](int work) {
@@ -410,12 +419,11 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(DwParams p) {
         __syncthreads();
         if (wi + walk.stride < walk.count) fetch(work + walk.stride);  // in flight while this tile is computed
         if (wave_on) {
+            const int lim_h = p.OH - oh0, lim_w = p.OW - ow0;
+            const unsigned out0 = (unsigned)(((b * p.OH + oh0) * p.OW + ow0) * p.C + c);
             for (int g0 = sub * 16; g0 < npos; g0 += 16 * WPG) {
-                int q = g0 + pix_l;
-                const bool qv = q < npos;
-                if (!qv) q = 0;
-                const int ohl = q / TW, owl = q - ohl * TW;
-                const T* bp = tile + (unsigned)(((ohl * S) * IWT + owl * S) * DWM_CBP + cl);
+                const int4 pe = ptab[g0 + pix_l];
+                const T* bp = reinterpret_cast<const T*>(reinterpret_cast<const char*>(tile) + pe.x) + cl;
                 dw_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 // one tap row of B operands ahead of the MFMAs that consume it, so the LDS latency is paid once per
                 // pixel group and not once per row
@@ -437,9 +445,8 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(DwParams p) {
 #pragma unroll
                     for (int kw = 0; kw < K; ++kw) cur[kw] = nxt[kw];
                 }
-                const int oh = oh0 + ohl, ow = ow0 + owl;
-                if (qv && cvalid && oh < p.OH && ow < p.OW) {
-                    const unsigned idx = (unsigned)(((b * p.OH + oh) * p.OW + ow) * p.C + c);
+                if (cvalid && pe.z < lim_h && pe.w < lim_w) {
+                    const unsigned idx = out0 + (unsigned)pe.y;
                     const f22 v = {v2f{acc[0], acc[1]}, v2f{acc[2], acc[3]}};
                     dw_epilogue_store<T>(p, idx, v, es, eh, em, er, st_s, st_q);
                 }
@@ -837,7 +844,9 @@ static int launch_mfma(DwParams& p, int K, int S, float* stats, int part_rows, h
     if (stats && gx > part_rows) gx = part_rows;
     *gx_out = gx;
     const int IHT = (p.TH - 1) * S + K, IWT = (p.TW - 1) * S + K;
-    const size_t lds = 256 * 8 * 4 + (size_t)IHT * IWT * (p.CB + 4) * 2;
+    size_t tile_bytes = (size_t)IHT * IWT * (p.CB + 4) * 2;
+    if (tile_bytes < 256 * 8 * 4) tile_bytes = 256 * 8 * 4;   // the statistics reduction reuses the tile
+    const size_t lds = (size_t)((p.TH * p.TW + 15) & ~15) * 16 + tile_bytes;
     dim3 grid(gx, cdiv(p.C, p.CB));
 #define MIA_DWM(K_, S_) \
     do { \
