@@ -105,7 +105,11 @@ def test_gemm_tn_prologue_gate(dtype):
 # ------------------------------------------------------------------ depthwise
 DW_CASES = [(3, 1, 2, 19, 19, 96), (3, 2, 2, 38, 38, 288), (5, 1, 2, 19, 19, 136), (5, 2, 2, 19, 19, 816),
             (5, 2, 1, 75, 75, 192), (3, 1, 1, 150, 150, 40), (3, 2, 1, 150, 150, 144), (3, 1, 3, 10, 10, 2304),
-            (5, 1, 3, 10, 10, 1392), (3, 1, 2, 2, 2, 24), (5, 2, 2, 4, 4, 48)]
+            (5, 1, 3, 10, 10, 1392), (3, 1, 2, 2, 2, 24), (5, 2, 2, 4, 4, 48),
+            # bf16 shapes of the matrix-core kernel: several tiles per image, 32- and 64-channel blocks, channel tails
+            # of 8, stride 2 onto a 38x38 map
+            (5, 1, 2, 38, 38, 288), (3, 1, 2, 38, 38, 72), (5, 1, 1, 19, 19, 816), (3, 2, 1, 75, 75, 144),
+            (3, 1, 2, 23, 17, 200)]
 
 
 def nchw(x):
