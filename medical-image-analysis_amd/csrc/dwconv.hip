@@ -32,6 +32,7 @@ struct DwParams {
     const float* erstd;
     float* stats;  // [gridDim.x][2][C] (nullable)
     int CB, TH, TW, tiles_h, tiles_w;
+    int gx, ncb;  // matrix-core kernels: 1-D grid of gx tile walkers x ncb channel blocks (see dw_decode_block)
 };
 
 // Four channels as two explicit 2-vectors (f22): each 2-vector op is one packed-f32 instruction on a naturally
@@ -168,19 +169,37 @@ __device__ __forceinline__ void dw_tile_commit(const TileRegs<T, NV>& t, T* tile
 struct TileWalk {
     int base, count, first, stride;
 };
-__device__ __forceinline__ TileWalk make_tile_walk(int total) {
+__device__ __forceinline__ TileWalk make_tile_walk(int total, int slot, int nslots) {
     TileWalk w;
-    if (gridDim.x & 7) {
-        w.base = 0; w.count = total; w.first = blockIdx.x; w.stride = gridDim.x;
+    if (nslots & 7) {
+        w.base = 0; w.count = total; w.first = slot; w.stride = nslots;
     } else {
-        const int per = (total + 7) >> 3, xcd = blockIdx.x & 7;
+        const int per = (total + 7) >> 3, xcd = slot & 7;
         w.base = xcd * per;
         w.count = total - w.base < per ? total - w.base : per;
         if (w.count < 0) w.count = 0;
-        w.first = blockIdx.x >> 3;
-        w.stride = gridDim.x >> 3;
+        w.first = slot >> 3;
+        w.stride = nslots >> 3;
     }
     return w;
+}
+__device__ __forceinline__ TileWalk make_tile_walk(int total) { return make_tile_walk(total, blockIdx.x, gridDim.x); }
+
+// 1-D grid of gx walkers x ncb channel blocks. A channel block's 64- or 128-byte run inside a pixel is not aligned
+// to the 128-byte cache line when the pixel stride (2*C bytes) is not a multiple of it (C = 288, 816, 1392), so
+// neighbouring channel blocks share lines; workgroup ids are dealt to the XCDs round-robin, so the blocks of one
+// walker are given ids with the same id%8 and adjacent dispatch order: they run on one XCD at about the same time
+// and the shared lines come out of its L2 instead of being fetched once per XCD.
+__device__ __forceinline__ void dw_decode_block(const DwParams& p, int& slot, int& cb) {
+    const int id = blockIdx.x;
+    if (p.gx & 7) {
+        cb = id % p.ncb;
+        slot = id / p.ncb;
+    } else {
+        const int r = id >> 3;
+        cb = r % p.ncb;
+        slot = (r / p.ncb) * 8 + (id & 7);
+    }
 }
 
 constexpr int DW_NV = 16;   // pixels per thread in a staged input tile (forward / data-gradient kernel)
@@ -348,7 +367,9 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(DwParams p) {
 
     const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c0 = blockIdx.y * DWM_CB;
+    int slot, cblk;
+    dw_decode_block(p, slot, cblk);
+    const int c0 = cblk * DWM_CB;
     const int cbv = (p.C - c0) < DWM_CB ? (p.C - c0) : DWM_CB;
     // staging role: thread (pt, cv) moves the 4-channel vector cv of pixels pt, pt+npt, ...
     const int cv = tid % nvec, pt = tid / nvec;
@@ -385,7 +406,7 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(DwParams p) {
         dw_tile_fetch<T, DWM_NV>(regs, x + (size_t)b * p.H * p.W * p.C, IHT, IWT, oh0 * S - PAD, ow0 * S - PAD, p.H,
                                  p.W, p.C, cst, st_ok, pt, npt);
     };
-    const TileWalk walk = make_tile_walk(total);
+    const TileWalk walk = make_tile_walk(total, slot, p.gx);
     if (walk.first < walk.count) fetch(walk.base + walk.first);
     // constants are loaded AFTER the first tile's loads are issued: one memory latency for both
     dw_s16x4 wA[K * K];
@@ -468,8 +489,8 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(DwParams p) {
                     bsum += red[(src + pl) * 8 + 4 + e];
                 }
             }
-            p.stats[((size_t)blockIdx.x * 2 + 0) * p.C + c0 + tid] = a;
-            p.stats[((size_t)blockIdx.x * 2 + 1) * p.C + c0 + tid] = bsum;
+            p.stats[((size_t)slot * 2 + 0) * p.C + c0 + tid] = a;
+            p.stats[((size_t)slot * 2 + 1) * p.C + c0 + tid] = bsum;
         }
     }
 }
@@ -695,6 +716,119 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, cons
     }
 }
 
+// bf16 weight gradient on the matrix cores. With channels on both matrix axes and output pixels on the reduction
+// axis,  D_t[c][c'] = sum_pix dY[pix][c] * X[pix + t][c'],  and the gradient of tap t is the diagonal of D_t. Both
+// operands need 4 consecutive PIXELS of one channel per lane while the staged tiles are pixel-major ([pixel][channel],
+// as they arrive from NHWC memory): gfx950's transposing LDS read delivers exactly that (a block of 4 pixel rows x
+// 16 channels per 16-lane group, each lane receiving one channel's four pixels). Per 16 pixels x 16 channels: one read
+// of dY, and per tap one read of X at the tap's offset plus one v_mfma_f32_16x16x16 into that tap's accumulator.
+// A wave owns 16 channels of the 64-channel block for the whole kernel, so the K*K accumulators never leave its
+// registers and no cross-wave reduction is needed; pixels beyond the tile read zeros of dY. The LDS pixel stride of
+// 160 bytes keeps the eight pixel rows of a 32-lane half on disjoint banks.
+constexpr int DWG_CB = 64;
+constexpr int DWG_CBP = 80;   // LDS pixel stride in elements
+constexpr int DWG_NVX = 16;   // staged input pixels per thread
+constexpr int DWG_NVD = 9;    // staged output-gradient pixels per thread
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void dwconv_bwdw_mfma_kernel(DwParams p, const void* dyv, float* slab) {
+    typedef bf16_t T;
+    typedef __attribute__((address_space(3))) dw_s16x4 lds_s16x4;
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int nvec = DWG_CB / 4, npt = 256 / nvec;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int TH = p.TH, TW = p.TW;
+    const int IHT = (TH - 1) * S + K, IWT = (TW - 1) * S + K;
+    const int npos = TH * TW, npos16 = (npos + 15) & ~15;
+    int* ptab = reinterpret_cast<int*>(smem);                      // [npos16] byte offset of the pixel's window origin
+    T* tile = reinterpret_cast<T*>(ptab + npos16);                 // [IHT*IWT][DWG_CBP]  pro(x)
+    T* dtile = tile + (size_t)IHT * IWT * DWG_CBP;                 // [npos16][DWG_CBP]   dY, zeros past the tile
+
+    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ dy = reinterpret_cast<const T*>(dyv);
+    const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
+    int slot, cblk;
+    dw_decode_block(p, slot, cblk);
+    const int c0 = cblk * DWG_CB;
+    const int cbv = (p.C - c0) < DWG_CB ? (p.C - c0) : DWG_CB;
+    const int cv = tid % nvec, pt = tid / nvec;
+    const bool st_ok = cv * 4 < cbv;
+    const bool has_pro = p.pscale != nullptr;
+    const bool wave_on = grp * 16 < cbv;
+    const f22 zero = {v2f{0.f, 0.f}, v2f{0.f, 0.f}}, one = {v2f{1.f, 1.f}, v2f{1.f, 1.f}};
+
+    for (int q = tid; q < npos16; q += 256) {
+        const int ohl = q / TW, owl = q - ohl * TW;
+        ptab[q] = q < npos ? ((ohl * S) * IWT + owl * S) * DWG_CBP * 2 : 0;
+    }
+    for (int i = npos * (DWG_CBP / 2) + tid; i < npos16 * (DWG_CBP / 2); i += 256)
+        reinterpret_cast<unsigned*>(dtile)[i] = 0u;   // never written again
+
+    dw_f32x4 acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int tiles_per_img = p.tiles_h * p.tiles_w;
+    const int total = p.B * tiles_per_img;
+    TileRegs<T, DWG_NVX> xregs;
+    TileRegs<T, DWG_NVD> dregs;
+    auto fetch = [&](int work) {
+        const int b = work / tiles_per_img;
+        const int tr = work - b * tiles_per_img;
+        const int trh = tr / p.tiles_w;
+        const int oh0 = trh * TH, ow0 = (tr - trh * p.tiles_w) * TW;
+        dw_tile_fetch<T, DWG_NVX>(xregs, x + (size_t)b * p.H * p.W * p.C, IHT, IWT, oh0 * S - PAD, ow0 * S - PAD, p.H,
+                                  p.W, p.C, c0 + cv * 4, st_ok, pt, npt);
+        dw_tile_fetch<T, DWG_NVD>(dregs, dy + (size_t)b * p.OH * p.OW * p.C, TH, TW, oh0, ow0, p.OH, p.OW, p.C,
+                                  c0 + cv * 4, st_ok, pt, npt);
+    };
+    const TileWalk walk = make_tile_walk(total, slot, p.gx);
+    if (walk.first < walk.count) fetch(walk.base + walk.first);
+    f22 psc = one, psh = zero;
+    if (has_pro && st_ok) { psc = load22<float>(p.pscale + c0 + cv * 4); psh = load22<float>(p.pshift + c0 + cv * 4); }
+    // transposed-read role: lane 4q+r of 16-lane group g addresses pixel row 4g+q of a 16-pixel chunk, channels 4r..4r+3
+    const int tg = lane >> 4, tq = (lane >> 2) & 3, tr4 = lane & 3;
+    const int chan_off = (grp * 16 + tr4 * 4) * 2;
+    for (int wi = walk.first; wi < walk.count; wi += walk.stride) {
+        const int work = walk.base + wi;
+        __syncthreads();
+        dw_tile_commit<T, DWG_NVX>(xregs, tile, IHT * IWT, cv, pt, npt, DWG_CBP, has_pro, psc, psh);
+        dw_tile_commit<T, DWG_NVD>(dregs, dtile, npos, cv, pt, npt, DWG_CBP, false, one, zero);
+        __syncthreads();
+        if (wi + walk.stride < walk.count) fetch(work + walk.stride);  // in flight while this tile is reduced
+        if (wave_on) {
+            for (int q0 = 0; q0 < npos; q0 += 16) {
+                const int q = q0 + tg * 4 + tq;
+                const char* dptr = reinterpret_cast<const char*>(dtile) + q * (DWG_CBP * 2) + chan_off;
+                const char* xptr = reinterpret_cast<const char*>(tile) + ptab[q] + chan_off;
+                const dw_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)dptr);
+#pragma unroll
+                for (int kh = 0; kh < K; ++kh) {
+                    const char* rp = xptr + kh * IWT * (DWG_CBP * 2);
+                    dw_s16x4 bv[K];
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw)
+                        bv[kw] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(rp + kw * (DWG_CBP * 2)));
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw)
+                        acc[kh * K + kw] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, bv[kw], acc[kh * K + kw], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // the diagonal: lane l holds D[4*(l/16)+i][l%16]; rows equal columns where (l%16)/4 == l/16, at i = l%4
+    if (wave_on) {
+        const int n = lane & 15;
+        const int ch = grp * 16 + n;
+        if ((n >> 2) == tg && ch < cbv) {
+            float* out = slab + ((size_t)slot * p.C + c0 + ch) * (K * K);
+            const int i = n & 3;
+#pragma unroll
+            for (int t = 0; t < K * K; ++t) out[t] = i == 0 ? acc[t][0] : i == 1 ? acc[t][1] : i == 2 ? acc[t][2] : acc[t][3];
+        }
+    }
+}
+
 // out[i] = sum over rows of slab[row][i]  (fixed order => reproducible)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int rows, long long n, float* out) {
     // 32 columns x 8 row groups per workgroup: the slab has few columns (C*K*K), so the rows carry the parallelism
@@ -822,9 +956,11 @@ static int dw_mfma_grid(int total, int chan_blocks, int K) {
     int target = resident / chan_blocks;
     if (target < 8) target = 8;
     static const bool big = getenv("MIA_DW_GRID_BIG") != nullptr;   // A/B switch for benchmarking
-    if (big || K == 3) return total < 8192 ? total : 8192;
+    if (big || K == 3) { const int g = total < 8192 ? total : 8192; return g >= 16 ? (g & ~7) : g; }
     const int per_wg = cdiv(total, target);
-    return cdiv(total, per_wg);
+    int gx = cdiv(total, per_wg);
+    if (gx >= 16) gx &= ~7;   // a multiple of eight lets dw_decode_block keep a walker's channel blocks on one XCD
+    return gx;
 }
 
 // bf16 only. Measured at batch 128 against the per-thread-patch kernel: ahead on maps up to 38x38 (1.2-1.7x on the
@@ -833,6 +969,12 @@ static int dw_mfma_grid(int total, int chan_blocks, int K) {
 static bool dw_use_mfma(int dtype, int C, int S, int OH, int OW) {
     static const bool off = getenv("MIA_DW_NO_MFMA") != nullptr;   // A/B switch for benchmarking
     return !off && dtype == MIA_BF16 && C % 4 == 0 && C >= 64 && OH * OW <= 1600 && !(S == 2 && OH * OW < 1024);
+}
+
+// measured: ahead of the per-thread kernel on the 5x5 layers (15-20 %), level or behind on 3x3
+static bool dw_use_mfma_w(int dtype, int C, int K, int S, int OH, int OW) {
+    static const bool off = getenv("MIA_DWW_NO_MFMA") != nullptr;   // A/B switch for benchmarking
+    return !off && dtype == MIA_BF16 && C % 4 == 0 && C >= 64 && OH * OW <= 1600 && K == 5 && !(S == 2 && OH * OW < 1024);
 }
 
 // p.x/p.y/p.H/p.W/p.OH/p.OW/flip/prologue/epilogue/stats set by the caller; fills the tile fields and launches.
@@ -847,7 +989,8 @@ static int launch_mfma(DwParams& p, int K, int S, float* stats, int part_rows, h
     size_t tile_bytes = (size_t)IHT * IWT * (p.CB + 4) * 2;
     if (tile_bytes < 256 * 8 * 4) tile_bytes = 256 * 8 * 4;   // the statistics reduction reuses the tile
     const size_t lds = (size_t)((p.TH * p.TW + 15) & ~15) * 16 + tile_bytes;
-    dim3 grid(gx, cdiv(p.C, p.CB));
+    p.gx = gx; p.ncb = cdiv(p.C, p.CB);
+    dim3 grid((unsigned)(p.gx * p.ncb));
 #define MIA_DWM(K_, S_) \
     do { \
         if (p.CB == 64) hipLaunchKernelGGL((dwconv_mfma_kernel<K_, S_, 64>), grid, dim3(256), lds, s, p); \
@@ -1009,6 +1152,43 @@ extern "C" int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int
     p.OH = (H + 2 * pad - K) / S + 1; p.OW = (W + 2 * pad - K) / S + 1;
     p.pscale = pscale; p.pshift = pshift; p.CB = pick_cb(C);
     const int elem = dtype == MIA_BF16 ? 2 : 4;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dw_use_mfma_w(dtype, C, K, S, p.OH, p.OW)) {
+        p.CB = DWG_CB;
+        // largest tile whose window and gradient pixels fit the staging registers; scored as in the forward kernel
+        double best = -1.0;
+        p.TH = 1; p.TW = 1;
+        for (int a = 1; a <= 16 && a <= p.OH + 3; ++a)
+            for (int b = 1; b <= 16 && b <= p.OW + 3; ++b) {
+                const int iht = (a - 1) * S + K, iwt = (b - 1) * S + K;
+                if (iht * iwt > 16 * DWG_NVX || a * b > 16 * DWG_NVD) continue;
+                const int nth = cdiv(p.OH, a), ntw = cdiv(p.OW, b);
+                const double useful = (double)p.OH * p.OW;
+                const double score = (useful / ((double)nth * ntw * iht * iwt)) * (useful / ((double)nth * ntw * a * b)) *
+                                     ((double)(a * b) / (cdiv(a * b, 16) * 16.0));
+                if (score > best) { best = score; p.TH = a; p.TW = b; }
+            }
+        p.tiles_h = cdiv(p.OH, p.TH); p.tiles_w = cdiv(p.OW, p.TW);
+        const int total = B * p.tiles_h * p.tiles_w;
+        const int ncb = cdiv(C, DWG_CB);
+        long long gx = 512 / ncb;                   // two workgroups per CU fit (registers, LDS)
+        if (gx < 8) gx = 8;
+        if (gx > total) gx = total;
+        if (gx > ws_floats / ((long long)C * K * K)) gx = ws_floats / ((long long)C * K * K);
+        const int IHT = (p.TH - 1) * S + K, IWT = (p.TW - 1) * S + K;
+        const int npos16 = (p.TH * p.TW + 15) & ~15;
+        const size_t lds = (size_t)npos16 * 4 + ((size_t)IHT * IWT + npos16) * DWG_CBP * 2;
+        p.gx = (int)gx; p.ncb = ncb;
+        dim3 grid((unsigned)(gx * ncb));
+        if (K == 3 && S == 1) hipLaunchKernelGGL((dwconv_bwdw_mfma_kernel<3, 1>), grid, dim3(256), lds, s, p, dy, ws);
+        else if (K == 3 && S == 2) hipLaunchKernelGGL((dwconv_bwdw_mfma_kernel<3, 2>), grid, dim3(256), lds, s, p, dy, ws);
+        else if (K == 5 && S == 1) hipLaunchKernelGGL((dwconv_bwdw_mfma_kernel<5, 1>), grid, dim3(256), lds, s, p, dy, ws);
+        else hipLaunchKernelGGL((dwconv_bwdw_mfma_kernel<5, 2>), grid, dim3(256), lds, s, p, dy, ws);
+        const long long nout = (long long)C * K * K;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(nout, 32)), dim3(256), 0, s, ws, (int)gx, nout, dw);
+        MIA_CHECK_LAUNCH("mia_dwconv_bwd_weight");
+        return 0;
+    }
     pick_tile(p.OH, p.OW, K, S, p.CB, elem, 1, DW_NVX, DW_NVD, dtype == MIA_BF16 ? 40960 : 81920, &p.TH, &p.TW);
     p.tiles_h = cdiv(p.OH, p.TH); p.tiles_w = cdiv(p.OW, p.TW);
     const int total = B * p.tiles_h * p.tiles_w;
@@ -1021,7 +1201,6 @@ extern "C" int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int
     const int IHT = (p.TH - 1) * S + K, IWT = (p.TW - 1) * S + K;
     const size_t lds = 256 * 4 * 4 + ((size_t)IHT * IWT + (size_t)p.TH * p.TW) * p.CB * elem;
     dim3 grid((unsigned)gx, ncb);
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define MIA_DWW(T_, K_, S_, PH_) \
     hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T_, K_, S_>), grid, dim3(256), lds, s, p, dy, ws)
     if (dtype == MIA_BF16) {
