@@ -10,6 +10,7 @@
 //
 // Storage type T is float (exact-f32 MFMA 16x16x4) or bf16 (MFMA 16x16x32); accumulation is fp32.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
@@ -145,6 +146,11 @@ __device__ __forceinline__ raw16 pro16(const raw16& r, bool silu, bool aff, bool
     if (gate) return Pro16<T>::template apply<false, false, true>(r, sc, sh, g);
     return r;
 }
+
+template <int V>
+struct IntTag {
+    static constexpr int value = V;
+};
 
 struct GemmNTParams {
     const void* A;
@@ -394,16 +400,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
         const bool vec_ok = (N % VEC) == 0 && (p.ldc % VEC) == 0;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
+            // the activation is chosen once per strip, not per element: left inside the loops, the test compiles to
+            // four scalar branches per output value, which cost more than the rest of the epilogue together
+            auto to_strip = [&](auto act_tag) {
+                constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
+                for (int j = 0; j < NT; ++j) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[i][j][r] + bias_r[j];
-                    if (p.epi_act == MIA_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.epi_act == MIA_ACT_SILU) v = siluf_(v);
-                    Cw[(lrow + r) * LDC + j * 16 + lcol] = from_f32<T>(v);
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[i][j][r] + bias_r[j];
+                        if (ACT == MIA_ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (ACT == MIA_ACT_SILU) v = siluf_(v);
+                        Cw[(lrow + r) * LDC + j * 16 + lcol] = from_f32<T>(v);
+                    }
                 }
-            }
+            };
+            if (p.epi_act == MIA_ACT_RELU) to_strip(IntTag<MIA_ACT_RELU>{});
+            else if (p.epi_act == MIA_ACT_SILU) to_strip(IntTag<MIA_ACT_SILU>{});
+            else to_strip(IntTag<MIA_ACT_NONE>{});
             __builtin_amdgcn_wave_barrier();
             const int mrow = m0 + wave * 16 * MT + i * 16;
             if (vec_ok) {
@@ -545,7 +559,8 @@ static int dispatch_nt(const GemmNTParams& p, int part_rows, hipStream_t stream)
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = w; }
     }
     // few row tiles: halve the tile height so that the grid still covers the chip
-    const bool small_m = (long long)cdiv(p.M, 128) * cdiv(p.N, best) < 384 && p.M > 64;
+    static const int small_thr = getenv("MIA_NT_SMALLM") ? atoi(getenv("MIA_NT_SMALLM")) : 384;   // A/B switch
+    const bool small_m = (long long)cdiv(p.M, 128) * cdiv(p.N, best) < small_thr && p.M > 64;
     switch (best) {
         case 32: return launch_nt<T, 2, 2>(p, part_rows, stream);
         case 48: return launch_nt<T, 2, 3>(p, part_rows, stream);

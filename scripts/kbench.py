@@ -70,6 +70,13 @@ CASES["gemm_proj6"] = lambda: gemm_case(B * 100, 384, 2304, True, True)
 CASES["gemm_proj11_noact"] = lambda: gemm_case(B * 75 * 75, 32, 192, True, True, act=ops.ACT_NONE)
 CASES["gemm_proj11_nogate"] = lambda: gemm_case(B * 75 * 75, 32, 192, True, True, use_gate=False)
 CASES["gemm_proj11_plain"] = lambda: gemm_case(B * 75 * 75, 32, 192, False, True)
+CASES["gemm_exp5_nostats"] = lambda: gemm_case(B * 100, 1392, 232, False, False)
+CASES["gemm_exp5_k32"] = lambda: gemm_case(B * 100, 1392, 32, False, True)
+CASES["gemm_exp5_k64"] = lambda: gemm_case(B * 100, 1392, 64, False, True)
+CASES["gemm_exp5_k128"] = lambda: gemm_case(B * 100, 1392, 128, False, True)
+CASES["gemm_exp5_k512"] = lambda: gemm_case(B * 100, 1392, 512, False, True)
+CASES["gemm_exp5_n144"] = lambda: gemm_case(B * 100, 144, 232, False, True)
+CASES["gemm_exp5_m4x"] = lambda: gemm_case(4 * B * 100, 1392, 232, False, True)
 CASES["gemm_dz10"] = lambda: gemm_case(B * 150 * 150, 144, 24, False, False)
 CASES["gemm_dz11"] = lambda: gemm_case(B * 75 * 75, 192, 32, False, False)
 
