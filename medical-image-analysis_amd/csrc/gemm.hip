@@ -559,8 +559,7 @@ static int dispatch_nt(const GemmNTParams& p, int part_rows, hipStream_t stream)
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = w; }
     }
     // few row tiles: halve the tile height so that the grid still covers the chip
-    static const int small_thr = getenv("MIA_NT_SMALLM") ? atoi(getenv("MIA_NT_SMALLM")) : 384;   // A/B switch
-    const bool small_m = (long long)cdiv(p.M, 128) * cdiv(p.N, best) < small_thr && p.M > 64;
+    const bool small_m = (long long)cdiv(p.M, 128) * cdiv(p.N, best) < 384 && p.M > 64;
     switch (best) {
         case 32: return launch_nt<T, 2, 2>(p, part_rows, stream);
         case 48: return launch_nt<T, 2, 3>(p, part_rows, stream);
