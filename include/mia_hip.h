@@ -46,7 +46,10 @@ int mia_gemm_tn(int dtype, const void* G, int ldg, const void* X, int ldx, float
                 void* stream);
 
 /* ---- depthwise k x k convolutions: timm conv_dw (k in {3,5}, stride in {1,2}, pad (k-1)/2, no bias) ----------
- * y[B,OH,OW,C] = dw(pro(x)[B,H,W,C]); pro = SiLU(x*pscale+pshift) when pscale != NULL; w is [C][k*k] fp32. */
+ * y[B,OH,OW,C] = dw(pro(x)[B,H,W,C]); pro = SiLU(x*pscale+pshift) when pscale != NULL; w is [C][k*k] fp32.
+ * bf16 with C >= 64 and OH*OW <= 1600 runs on the matrix cores (forward, stride-1 data gradient, 5x5 weight
+ * gradient): there the taps are rounded to bf16 like every other operand (autocast semantics, fp32 accumulation);
+ * all other cases multiply by the fp32 taps. fp32 tensors never take that path. */
 int mia_dwconv_fwd(int dtype, const void* x, int B, int H, int W, int C, const float* pscale, const float* pshift,
                    const float* w, int K, int S, void* y, float* stats, int part_rows, void* stream);
 /* dx[B,H,W,C] from dy[B,OH,OW,C]. With yfwd != NULL the epilogue turns it into the gradient w.r.t. the
