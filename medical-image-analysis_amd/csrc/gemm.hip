@@ -764,7 +764,24 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
         commit(ch);
         __syncthreads();
         if (ch + 1 < chunk_end) prefetch(ch + 1);  // in flight during the MFMAs below
-        if (mt_cnt > 0 && nt_cnt > 0) {
+        if (mt_cnt == MT && nt_cnt == NT) {
+            // full wave tile: no per-MFMA tests (left in, each compiles to a scalar branch around its MFMA and the
+            // branches cost more than the MFMAs)
+#pragma unroll
+            for (int kk = 0; kk < BR / M_::KSTEP; ++kk) {
+                typename M_::Frag a[MT], b[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    a[i] = M_::load_t(Gs + kk * M_::KSTEP * LD + wr * WN + i * 16, LD, lane);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    b[j] = M_::load_t(Xs + kk * M_::KSTEP * LD + wc * WK + j * 16, LD, lane);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]);
+            }
+        } else if (mt_cnt > 0 && nt_cnt > 0) {
 #pragma unroll
             for (int kk = 0; kk < BR / M_::KSTEP; ++kk) {
                 typename M_::Frag a[MT], b[NT];
