@@ -30,11 +30,14 @@ struct AdamWChunk {
 };
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamWChunk c, const float* __restrict__ dev_hyper) {
-    // step-dependent factors from device memory when given: a captured graph replays fixed kernel arguments
+    // step-dependent factors from device memory when given: a captured graph replays fixed kernel arguments.
+    // (Kept in locals: assigning to fields of `c` would force a private copy of the whole 2 KB argument block in
+    // every lane -- measured at 73 us instead of 13 us a launch.)
+    float lr_wd_keep = c.lr_wd_keep, step_size = c.step_size, inv_sqrt_bc2 = c.inv_sqrt_bc2;
     if (dev_hyper) {
-        c.lr_wd_keep = dev_hyper[0];
-        c.step_size = dev_hyper[1];
-        c.inv_sqrt_bc2 = dev_hyper[2];
+        lr_wd_keep = dev_hyper[0];
+        step_size = dev_hyper[1];
+        inv_sqrt_bc2 = dev_hyper[2];
     }
     // wave-uniform scan: which tensor does this block belong to
     int t = 0;
@@ -48,11 +51,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamWChunk c, const float* _
     const float omb1 = c.omb1, omb2 = c.omb2;
     auto upd = [&](float& pp, float gg, float& mm, float& vv) {
         gg *= c.grad_scale;
-        pp *= c.lr_wd_keep;
+        pp *= lr_wd_keep;
         mm = mm + omb1 * (gg - mm);          // lerp(m, g, 1-b1)
         vv = vv * c.beta2 + omb2 * gg * gg;
-        const float denom = sqrtf(vv) * c.inv_sqrt_bc2 + c.eps;
-        pp -= c.step_size * (mm / denom);
+        const float denom = sqrtf(vv) * inv_sqrt_bc2 + c.eps;
+        pp -= step_size * (mm / denom);
     };
     const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
 #pragma unroll
