@@ -77,6 +77,9 @@ CASES["gemm_exp5_k128"] = lambda: gemm_case(B * 100, 1392, 128, False, True)
 CASES["gemm_exp5_k512"] = lambda: gemm_case(B * 100, 1392, 512, False, True)
 CASES["gemm_exp5_n144"] = lambda: gemm_case(B * 100, 144, 232, False, True)
 CASES["gemm_exp5_m4x"] = lambda: gemm_case(4 * B * 100, 1392, 232, False, True)
+CASES["gemm_exp3"] = lambda: gemm_case(B * 19 * 19, 576, 96, False, True)
+CASES["gemm_exp2"] = lambda: gemm_case(B * 38 * 38, 288, 48, False, True)
+CASES["gemm_dz4"] = lambda: gemm_case(B * 19 * 19, 816, 136, False, False)
 CASES["gemm_dz10"] = lambda: gemm_case(B * 150 * 150, 144, 24, False, False)
 CASES["gemm_dz11"] = lambda: gemm_case(B * 75 * 75, 192, 32, False, False)
 
