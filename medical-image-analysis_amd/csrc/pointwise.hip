@@ -539,8 +539,67 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(T* G, const T* Y,
                                                                const float* scale, const float* shift, int act,
                                                                const float* gate, const float* dpool,
                                                                unsigned vec_per_img, const float* ca, const float* cb,
-                                                               const float* cd) {
+                                                               const float* cd, int fixed_c) {
     const unsigned cvec = (unsigned)C / W;
+    if (fixed_c) {
+        // The grid stride is a multiple of the vectors per row (the host sizes the grid so), hence this thread sees
+        // the same channels in every iteration: the five per-channel coefficient vectors are loaded once instead of
+        // 160 bytes of them per 32 bytes of tensor, and the channel index needs no division in the loop.
+        constexpr int Q = W / 4;
+        unsigned i = blockIdx.x * 256 + threadIdx.x;
+        const int c = (int)(i % cvec) * W;
+        const bool silu = act == MIA_ACT_SILU;
+        f22 sc[Q], sh[Q], a[Q], bb[Q], d[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            sc[q] = silu ? load22<float>(scale + c + 4 * q) : f22{v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+            sh[q] = silu ? load22<float>(shift + c + 4 * q) : f22{v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+            a[q] = load22<float>(ca + c + 4 * q);
+            bb[q] = load22<float>(cb + c + 4 * q);
+            d[q] = load22<float>(cd + c + 4 * q);
+        }
+        const float inv_vpi = 1.0f / (float)vec_per_img;
+        for (; i < nvec; i += gridDim.x * 256) {
+            const size_t idx = (size_t)i * W;
+            f22 g[Q], y[Q];
+            if constexpr (W == 8) {
+                load44<T>(G + idx, g[0], g[1]);
+                load44<T>(Y + idx, y[0], y[1]);
+            } else {
+                g[0] = load22<T>(G + idx);
+                y[0] = load22<T>(Y + idx);
+            }
+            if (gate) {
+                // image of this vector: float estimate plus one correction (exact for i < 2^24, else the division)
+                unsigned img;
+                if (nvec < (1u << 24)) {
+                    img = (unsigned)((float)i * inv_vpi);
+                    const long long rem = (long long)i - (long long)img * vec_per_img;
+                    if (rem < 0) --img;
+                    else if (rem >= (long long)vec_per_img) ++img;
+                } else {
+                    img = i / vec_per_img;
+                }
+                const size_t go = (size_t)img * C + c;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const f22 gt = load22<float>(gate + go + 4 * q), dp = load22<float>(dpool + go + 4 * q);
+                    g[q].lo = g[q].lo * gt.lo + dp.lo; g[q].hi = g[q].hi * gt.hi + dp.hi;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                if (silu) {
+                    g[q].lo *= silu_grad2(y[q].lo * sc[q].lo + sh[q].lo);
+                    g[q].hi *= silu_grad2(y[q].hi * sc[q].hi + sh[q].hi);
+                }
+                g[q] = f22{a[q].lo * g[q].lo + bb[q].lo * y[q].lo + d[q].lo, a[q].hi * g[q].hi + bb[q].hi * y[q].hi + d[q].hi};
+            }
+            if constexpr (W == 8) store44<T>(G + idx, g[0], g[1]);
+            else store22<T>(G + idx, g[0]);
+        }
+        return;
+    }
     auto four = [&](f22& g, const f22& y, int c, size_t go) {
         if (gate) {
             const f22 gt = load22<float>(gate + go), dp = load22<float>(dpool + go);
@@ -588,11 +647,21 @@ extern "C" int mia_bn_act_bwd_apply(int dtype, void* G, const void* Y, long long
     MIA_CHECK_ARG(nvec < (1LL << 32), "mia_bn_act_bwd_apply: tensor too large");
     long long blocks = (nvec + 255) / 256;
     if (blocks > 8192) blocks = 8192;
+    // a grid whose stride (blocks*256 vectors) is a multiple of the vectors per row keeps every thread on fixed
+    // channels: blocks must be a multiple of cvec / gcd(cvec, 256)
+    int fixed_c = 0;
+    {
+        const long long cvec = C / W;
+        long long a_ = cvec, b_ = 256;
+        while (b_) { const long long t = a_ % b_; a_ = b_; b_ = t; }
+        const long long unit = cvec / a_;
+        if (unit <= blocks) { blocks = blocks / unit * unit; fixed_c = 1; }
+    }
     const unsigned vpi = (unsigned)((long long)(rows_per_img > 0 ? rows_per_img : 1) * C / W);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define MIA_APPLY(T_, W_)                                                                                          \
     hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T_, W_>), dim3((unsigned)blocks), dim3(256), 0, s, (T_*)G, (const T_*)Y, \
-                       (unsigned)nvec, C, scale, shift, act, gate, dpool, vpi, ca, cb, cd)
+                       (unsigned)nvec, C, scale, shift, act, gate, dpool, vpi, ca, cb, cd, fixed_c)
     if (dtype == MIA_BF16) { if (wide) MIA_APPLY(bf16_t, 8); else MIA_APPLY(bf16_t, 4); }
     else { if (wide) MIA_APPLY(float, 8); else MIA_APPLY(float, 4); }
 #undef MIA_APPLY
