@@ -289,8 +289,43 @@ __global__ __launch_bounds__(256) void affine2_kernel(const T* X, const T* Y, co
 template <typename T>
 __global__ __launch_bounds__(256) void affine2_wide_kernel(const T* X, const T* Y, const T* Res, T* Out, unsigned nvec8,
                                                            int C, const float* a, const float* b, const float* d,
-                                                           int act) {
+                                                           int act, int fixed_c) {
     const unsigned cvec = (unsigned)C >> 3;
+    if (fixed_c) {
+        // grid stride = a multiple of the vectors per row (host): fixed channels per thread, coefficients in registers
+        unsigned i = blockIdx.x * 256 + threadIdx.x;
+        const int c = (int)(i % cvec) << 3;
+        const f22 zero = {v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+        const f22 a0 = load22<float>(a + c), a1 = load22<float>(a + c + 4);
+        const f22 d0 = load22<float>(d + c), d1 = load22<float>(d + c + 4);
+        const f22 b0 = Y ? load22<float>(b + c) : zero, b1 = Y ? load22<float>(b + c + 4) : zero;
+        for (; i < nvec8; i += gridDim.x * 256) {
+            const size_t idx = (size_t)i * 8;
+            f22 x0, x1;
+            load44<T>(X + idx, x0, x1);
+            f22 o0 = {x0.lo * a0.lo + d0.lo, x0.hi * a0.hi + d0.hi}, o1 = {x1.lo * a1.lo + d1.lo, x1.hi * a1.hi + d1.hi};
+            if (Y) {
+                f22 y0, y1;
+                load44<T>(Y + idx, y0, y1);
+                o0.lo += y0.lo * b0.lo; o0.hi += y0.hi * b0.hi;
+                o1.lo += y1.lo * b1.lo; o1.hi += y1.hi * b1.hi;
+            }
+            if (act == MIA_ACT_SILU) {
+                o0.lo = silu2(o0.lo); o0.hi = silu2(o0.hi); o1.lo = silu2(o1.lo); o1.hi = silu2(o1.hi);
+            } else if (act == MIA_ACT_RELU) {
+                const v2f z = {0.f, 0.f};
+                o0.lo = __builtin_elementwise_max(o0.lo, z); o0.hi = __builtin_elementwise_max(o0.hi, z);
+                o1.lo = __builtin_elementwise_max(o1.lo, z); o1.hi = __builtin_elementwise_max(o1.hi, z);
+            }
+            if (Res) {
+                f22 r0, r1;
+                load44<T>(Res + idx, r0, r1);
+                o0.lo += r0.lo; o0.hi += r0.hi; o1.lo += r1.lo; o1.hi += r1.hi;
+            }
+            store44<T>(Out + idx, o0, o1);
+        }
+        return;
+    }
     for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < nvec8; i += gridDim.x * 256) {
         const size_t idx = (size_t)i * 8;
         const int c = (int)(i % cvec) << 3;
@@ -336,12 +371,20 @@ extern "C" int mia_affine2(int dtype, const void* X, const void* Y, const void* 
         const long long nvec8 = nvec / 2;
         long long wblocks = (nvec8 + 255) / 256;
         if (wblocks > 16384) wblocks = 16384;
+        int fixed_c = 0;
+        {
+            const long long cvec = C / 8;
+            long long a_ = cvec, b_ = 256;
+            while (b_) { const long long t = a_ % b_; a_ = b_; b_ = t; }
+            const long long unit = cvec / a_;
+            if (unit <= wblocks) { wblocks = wblocks / unit * unit; fixed_c = 1; }
+        }
         if (dtype == MIA_BF16)
             hipLaunchKernelGGL(affine2_wide_kernel<bf16_t>, dim3((unsigned)wblocks), dim3(256), 0, s, (const bf16_t*)X,
-                               (const bf16_t*)Y, (const bf16_t*)Res, (bf16_t*)Out, (unsigned)nvec8, C, a, b, d, act);
+                               (const bf16_t*)Y, (const bf16_t*)Res, (bf16_t*)Out, (unsigned)nvec8, C, a, b, d, act, fixed_c);
         else
             hipLaunchKernelGGL(affine2_wide_kernel<float>, dim3((unsigned)wblocks), dim3(256), 0, s, (const float*)X,
-                               (const float*)Y, (const float*)Res, (float*)Out, (unsigned)nvec8, C, a, b, d, act);
+                               (const float*)Y, (const float*)Res, (float*)Out, (unsigned)nvec8, C, a, b, d, act, fixed_c);
         MIA_CHECK_LAUNCH("mia_affine2");
         return 0;
     }
