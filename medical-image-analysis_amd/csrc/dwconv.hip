@@ -1162,6 +1162,8 @@ extern "C" int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int
             for (int b = 1; b <= 16 && b <= p.OW + 3; ++b) {
                 const int iht = (a - 1) * S + K, iwt = (b - 1) * S + K;
                 if (iht * iwt > 16 * DWG_NVX || a * b > 16 * DWG_NVD) continue;
+                // dynamic LDS of a launch without an opt-in attribute is limited to 64 KiB
+                if ((size_t)((a * b + 15) & ~15) * 4 + ((size_t)iht * iwt + ((a * b + 15) & ~15)) * DWG_CBP * 2 > 64 * 1024) continue;
                 const int nth = cdiv(p.OH, a), ntw = cdiv(p.OW, b);
                 const double useful = (double)p.OH * p.OW;
                 const double score = (useful / ((double)nth * ntw * iht * iwt)) * (useful / ((double)nth * ntw * a * b)) *

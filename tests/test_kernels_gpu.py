@@ -109,7 +109,7 @@ DW_CASES = [(3, 1, 2, 19, 19, 96), (3, 2, 2, 38, 38, 288), (5, 1, 2, 19, 19, 136
             # bf16 shapes of the matrix-core kernel: several tiles per image, 32- and 64-channel blocks, channel tails
             # of 8, stride 2 onto a 38x38 map
             (5, 1, 2, 38, 38, 288), (3, 1, 2, 38, 38, 72), (5, 1, 1, 19, 19, 816), (3, 2, 1, 75, 75, 144),
-            (3, 1, 2, 23, 17, 200)]
+            (3, 1, 2, 23, 17, 200), (5, 1, 2, 24, 24, 128), (5, 1, 1, 36, 36, 64)]
 
 
 def nchw(x):
