@@ -204,6 +204,13 @@ int mia_resize_normalize_u8(const uint8_t* src, int N, int h, int w, int ch, flo
  *      flags_ws: int32[n_slices] scratch. elem_bytes in {1,2,4}; is_float selects IEEE compare for 4-byte data. */
 int mia_zero_slice_filter(const void* vol, int elem_bytes, int is_float, long long n_slices, long long slice_elems,
                           int* flags_ws, uint8_t* keep, int* idx, int* count, void* stream);
+/* The same filter for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc. No counterpart in the reference. The flag words live in a device array built into
+ * the library (256 KiB per GPU, held until the process ends) instead of flags_ws; the entry point allocates nothing and
+ * rejects n_slices > 65535. Calls on one GPU share that array: calls that overlap on the same GPU race. Results are
+ * identical to mia_zero_slice_filter. */
+int mia_zero_slice_filter_static(const void* vol, int elem_bytes, int is_float, long long n_slices,
+                                 long long slice_elems, uint8_t* keep, int* idx, int* count, void* stream);
 /* out[k] = vol[idx[k]] for k < count[0] (count stays on the device: no host round trip). */
 int mia_gather_slices(const void* vol, int elem_bytes, long long n_slices, long long slice_elems, const int* idx,
                       const int* count, void* out, void* stream);

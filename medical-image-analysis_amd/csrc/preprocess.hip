@@ -7,6 +7,7 @@
 // operations (x - 255*mean) * (1/(255*std)). Floating-point contraction is disabled in this file:
 // an fma in the coordinate computation would change which source pixel a destination maps to.
 #include "common.h"
+#include <mutex>
 
 #pragma clang fp contract(off)
 
@@ -303,6 +304,57 @@ extern "C" int mia_zero_slice_filter(const void* vol, int elem_bytes, int is_flo
     hipLaunchKernelGGL(slice_compact_kernel, dim3(1), dim3(256), 0, s, flags_ws, n_slices, keep, idx, count);
     MIA_CHECK_LAUNCH("mia_zero_slice_filter");
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same filter for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+// loops): the per-slice flag words live in a file-scope device array instead of a caller-provided workspace.
+// Each GPU holds its own copy of the array (256 KiB, until the process ends) at its own address, so the address is
+// resolved once per device with that device current and kept; host code only ever uses the resolved pointer.
+// Calls on one GPU share the array: two calls that overlap on the same GPU (different streams) race.
+// ------------------------------------------------------------------------------------------------
+#define MIA_ZSF_STATIC_MAX_SLICES 65535
+#define MIA_MAX_DEVICES 64
+static __device__ __align__(256) int scratch[MIA_ZSF_STATIC_MAX_SLICES + 1];
+static int* g_scratch_ptr[MIA_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+// Device address of `scratch` on the current device (nullptr + error message on failure).
+static int* zsf_scratch_ptr() {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= MIA_MAX_DEVICES) {
+        mia_set_error("mia_zero_slice_filter_static: hipGetDevice failed or device %d out of range: %s", dev,
+                      hipGetErrorString(e));
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        int* ptr = nullptr;
+        e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            mia_set_error("mia_zero_slice_filter_static: hipGetSymbolAddress failed on device %d: %s", dev,
+                          hipGetErrorString(e));
+            return nullptr;
+        }
+        g_scratch_ptr[dev] = ptr;
+    }
+    return g_scratch_ptr[dev];
+}
+
+extern "C" int mia_zero_slice_filter_static(const void* vol, int elem_bytes, int is_float, long long n_slices,
+                                            long long slice_elems, uint8_t* keep, int* idx, int* count,
+                                            void* stream) {
+    MIA_CHECK_ARG(vol && keep && idx && count, "mia_zero_slice_filter_static: null argument");
+    MIA_CHECK_ARG(n_slices > 0 && slice_elems > 0, "mia_zero_slice_filter_static: bad shape");
+    MIA_CHECK_ARG(n_slices <= MIA_ZSF_STATIC_MAX_SLICES,
+                  "mia_zero_slice_filter_static: %lld slices exceed the built-in scratch (%d slices per call); "
+                  "split the volume or use mia_zero_slice_filter with a workspace",
+                  n_slices, MIA_ZSF_STATIC_MAX_SLICES);
+    int* ptr = zsf_scratch_ptr();
+    if (!ptr) return -3;
+    // the array keeps the previous call's flags: mia_zero_slice_filter clears the first n_slices words first
+    return mia_zero_slice_filter(vol, elem_bytes, is_float, n_slices, slice_elems, ptr, keep, idx, count, stream);
 }
 
 // out[k] = vol[idx[k]] for k < count[0]; grid = (chunks, n_slices) and rows beyond count exit at once.
