@@ -49,7 +49,9 @@ int mia_gemm_tn(int dtype, const void* G, int ldg, const void* X, int ldx, float
  * y[B,OH,OW,C] = dw(pro(x)[B,H,W,C]); pro = SiLU(x*pscale+pshift) when pscale != NULL; w is [C][k*k] fp32.
  * bf16 with C >= 64 and OH*OW <= 1600 runs on the matrix cores (forward, stride-1 data gradient, 5x5 weight
  * gradient): there the taps are rounded to bf16 like every other operand (autocast semantics, fp32 accumulation);
- * all other cases multiply by the fp32 taps. fp32 tensors never take that path. */
+ * all other cases multiply by the fp32 taps. fp32 tensors never take that path. Two environment variables, read once
+ * per process, keep the fp32-tap kernels everywhere (for A/B measurements of speed and of bf16 gradient fidelity):
+ * MIA_DW_NO_MFMA (forward and data gradient) and MIA_DWW_NO_MFMA (weight gradient). */
 int mia_dwconv_fwd(int dtype, const void* x, int B, int H, int W, int C, const float* pscale, const float* pshift,
                    const float* w, int K, int S, void* y, float* stats, int part_rows, void* stream);
 /* dx[B,H,W,C] from dy[B,OH,OW,C]. With yfwd != NULL the epilogue turns it into the gradient w.r.t. the
@@ -177,7 +179,9 @@ int mia_dropout_f32(float* x, const float* relu_ref, long long n, float pdrop, u
                     const unsigned long long* seed_offset, void* stream);
 /* out[c] = sum_r x[r][c]: bias gradients. */
 int mia_colsum(int dtype, const void* x, long long R, int C, int ld, float* out, void* stream);
-/* nn.CrossEntropyLoss (src/loss.py:147; train.py:352): mean loss and d loss / d logits (zero padded to ldd columns). */
+/* nn.CrossEntropyLoss (src/loss.py:147; train.py:352): mean loss and d loss / d logits (zero padded to ldd columns).
+ * A label of -100 (the default ignore_index) drops its row from the sum and the divisor; any other label outside
+ * [0, n) (a device-side assert in torch) gives a zero gradient row and a NaN loss, and is never used as an index. */
 int mia_softmax_ce(const float* logits, int ld, const long long* labels, int B, int n, float* loss, float* dlogits,
                    int ldd, void* stream);
 

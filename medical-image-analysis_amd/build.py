@@ -17,7 +17,9 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    # the public header too: _lib.py derives every ctypes prototype from it, so a library older than the header
+    # could be called with the wrong argument list
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "mia_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

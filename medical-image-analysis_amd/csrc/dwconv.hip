@@ -955,8 +955,7 @@ static int dw_mfma_grid(int total, int chan_blocks, int K) {
     const int resident = 256 * (K == 5 ? 3 : 4);
     int target = resident / chan_blocks;
     if (target < 8) target = 8;
-    static const bool big = getenv("MIA_DW_GRID_BIG") != nullptr;   // A/B switch for benchmarking
-    if (big || K == 3) { const int g = total < 8192 ? total : 8192; return g >= 16 ? (g & ~7) : g; }
+    if (K == 3) { const int g = total < 8192 ? total : 8192; return g >= 16 ? (g & ~7) : g; }
     const int per_wg = cdiv(total, target);
     int gx = cdiv(total, per_wg);
     if (gx >= 16) gx &= ~7;   // a multiple of eight lets dw_decode_block keep a walker's channel blocks on one XCD
@@ -967,13 +966,14 @@ static int dw_mfma_grid(int total, int chan_blocks, int K) {
 // 5x5 layers), behind on the 75x75 and 150x150 maps (streaming-bound there, and the 16-pixel staging tiles of this
 // kernel re-read more halo), on layers narrower than 64 channels and on small stride-2 maps that tile badly.
 static bool dw_use_mfma(int dtype, int C, int S, int OH, int OW) {
-    static const bool off = getenv("MIA_DW_NO_MFMA") != nullptr;   // A/B switch for benchmarking
+    // documented switch (include/mia_hip.h): keeps the fp32-tap per-thread kernels, read once per process
+    static const bool off = getenv("MIA_DW_NO_MFMA") != nullptr;
     return !off && dtype == MIA_BF16 && C % 4 == 0 && C >= 64 && OH * OW <= 1600 && !(S == 2 && OH * OW < 1024);
 }
 
 // measured: ahead of the per-thread kernel on the 5x5 layers (15-20 %), level or behind on 3x3
 static bool dw_use_mfma_w(int dtype, int C, int K, int S, int OH, int OW) {
-    static const bool off = getenv("MIA_DWW_NO_MFMA") != nullptr;   // A/B switch for benchmarking
+    static const bool off = getenv("MIA_DWW_NO_MFMA") != nullptr;   // documented switch, as above
     return !off && dtype == MIA_BF16 && C % 4 == 0 && C >= 64 && OH * OW <= 1600 && K == 5 && !(S == 2 && OH * OW < 1024);
 }
 

@@ -804,26 +804,43 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, long long R, in
 }
 
 // softmax cross-entropy, mean over the batch, with its gradient (d loss / d logits). One workgroup.
+// Labels follow nn.CrossEntropyLoss: -100 (its default ignore_index) drops the row from the sum and from the divisor
+// (all rows ignored: 0/0 = NaN, as in torch). Any other label outside [0, n) is an error there (a device-side assert);
+// here the row contributes no gradient, is never used as an index, and the loss comes back NaN so the mistake shows.
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* logits, const long long* labels, int B, int n,
                                                          int ld, float* loss, float* dlogits, int ldd) {
-    __shared__ float red[4];
+    __shared__ float red[4], cnt[4], bad[4];
+    float valid = 0.f, invalid = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const long long y = labels[b];
+        if (y >= 0 && y < n) valid += 1.f;
+        else if (y != -100) invalid += 1.f;
+    }
+    valid = wave_sum(valid);
+    invalid = wave_sum(invalid);
+    if ((threadIdx.x & 63) == 0) { cnt[threadIdx.x >> 6] = valid; bad[threadIdx.x >> 6] = invalid; }
+    __syncthreads();
+    const float count = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    const float nbad = bad[0] + bad[1] + bad[2] + bad[3];
+    const float inv = 1.0f / count;
     float acc = 0.f;
     for (int b = threadIdx.x; b < B; b += 256) {
         const float* z = logits + (size_t)b * ld;
+        const long long y = labels[b];
+        const bool use = y >= 0 && y < n;
         float m = -INFINITY;
         for (int j = 0; j < n; ++j) m = fmaxf(m, z[j]);
         float l = 0.f;
         for (int j = 0; j < n; ++j) l += expf(z[j] - m);
         const float lse = m + logf(l);
-        const int y = (int)labels[b];
-        acc += lse - z[y];
+        if (use) acc += lse - z[y];
         for (int j = 0; j < ldd; ++j)
-            dlogits[(size_t)b * ldd + j] = j < n ? (expf(z[j] - lse) - (j == y ? 1.f : 0.f)) / (float)B : 0.f;
+            dlogits[(size_t)b * ldd + j] = (use && j < n) ? (expf(z[j] - lse) - (j == y ? 1.f : 0.f)) * inv : 0.f;
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+    if (threadIdx.x == 0) loss[0] = nbad > 0.f ? __builtin_nanf("") : (red[0] + red[1] + red[2] + red[3]) / count;
 }
 
 // =================================================================================================

@@ -7,22 +7,47 @@ parameter-heavy late stages first), each bucket's all-reduce is launched asynchr
 last gradient lands, and `finish()` makes the compute stream wait for all of them before the optimizer
 step. xGMI is point-to-point, so a few large buckets (default 16 MiB of the ~44 MB of fp32 gradients)
 keep every link busy without paying per-collective latency many times.
+
+Collectives are matched across ranks by construction: every step, every rank all-reduces EVERY bucket, in
+bucket order. A bucket goes out during backward as soon as its last gradient has landed and all earlier
+buckets are out; `finish()` launches the rest, with zeros in the slots of parameters that got no gradient
+on this rank. A rank-dependent set of used parameters therefore cannot leave one rank waiting in a
+collective the others never start. The price: a bucket holding a parameter that gets no gradient only goes
+out at `finish()` together with every later bucket (no overlap for those), so pass only the parameters the
+step trains (the trunk and the active head), not every head of a multi-head model.
 """
+import os
+import sys
+import time
 from typing import Iterable, List
 
 import torch
 import torch.distributed as dist
 
 
+def _trace(msg):
+    if os.environ.get("MIA_DDP_TRACE"):
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        print(f"[ddp rank {rank}] {time.strftime('%H:%M:%S')} {msg}", file=sys.stderr, flush=True)
+
+
 class GradReducer:
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 16 << 20, group=None):
+    """params: the parameters being trained. always_exchange: run the pack / all-reduce / wait path even with a single
+    rank (where the exchange is the identity), so that one GPU exercises the code the multi-GPU job runs."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 16 << 20, group=None,
+                 always_exchange: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if always_exchange and not dist.is_initialized():
+            raise RuntimeError("always_exchange needs an initialised process group")
+        self.exchange = self.world > 1 or always_exchange
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
-        self.buckets = []       # list of dicts: flat, views{param_id: view}, pending, count
+        self.buckets = []       # list of dicts: flat, views{param_id: view}, pending, count, ready, launched
         self._param_bucket = {}
         self._works = []
         self._avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self._in_backward = False
         cur, cur_bytes = [], 0
         for p in reversed(self.params):
             nbytes = p.numel() * 4
@@ -33,6 +58,7 @@ class GradReducer:
             cur_bytes += nbytes
         if cur:
             self._close(cur)
+        self._next = 0          # buckets [0, _next) are out this step
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
 
     def _close(self, plist):
@@ -42,57 +68,87 @@ class GradReducer:
         for p in plist:
             views[id(p)] = flat[off:off + p.numel()].view_as(p)
             off += p.numel()
-        b = {"flat": flat, "views": views, "count": len(plist), "pending": len(plist), "ready": []}
+        b = {"flat": flat, "views": views, "count": len(plist), "pending": len(plist), "ready": [], "launched": False,
+             "index": len(self.buckets)}
         for p in plist:
             self._param_bucket[id(p)] = b
         self.buckets.append(b)
 
     def broadcast_parameters(self, module: torch.nn.Module, src: int = 0):
-        """One-time broadcast of parameters and buffers from rank `src` (replicas start identical)."""
-        if self.world == 1:
+        """One-time broadcast of parameters and buffers from rank `src` (replicas start identical). Tensors are
+        packed per dtype into one flat buffer each, so the ~1,000 tensors of the model cost a handful of
+        collectives instead of one each."""
+        if not self.exchange:
             return
+        by_dtype = {}
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src, group=self.group)
+            by_dtype.setdefault((t.dtype, t.device), []).append(t.data)
+        for (dtype, device), tensors in by_dtype.items():
+            flat = torch.cat([t.reshape(-1) for t in tensors])
+            dist.broadcast(flat, src, group=self.group)
+            off = 0
+            for t in tensors:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))
+                off += n
+            _trace(f"broadcast {dtype} x{len(tensors)} ({flat.numel()} elements) done")
 
     def _hook(self, p: torch.nn.Parameter):
-        if self.world == 1:
+        if not self.exchange:
             return  # nothing to exchange: gradients stay where autograd put them
         b = self._param_bucket[id(p)]
+        if b["launched"] or b["pending"] == 0:
+            raise RuntimeError(
+                "GradReducer: a parameter received a second gradient before finish() — its bucket's all-reduce is "
+                "already in flight. Call finish() after every backward (gradient accumulation across several "
+                "backward passes is not supported by the bucketed exchange).")
+        if not self._in_backward:
+            self._in_backward = True
+            _trace("first hook of this backward")
         b["ready"].append(p)
         b["pending"] -= 1
-        if b["pending"] == 0:
-            self._launch(b)
+        while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
+            self._launch(self.buckets[self._next])
 
     def _launch(self, b):
         # one fused multi-tensor copy packs the bucket, then its all-reduce starts while backward continues
         ready = b["ready"]
-        views = [b["views"][id(p)] for p in ready]
-        torch._foreach_copy_(views, [p.grad for p in ready])
-        for p, v in zip(ready, views):
-            p.grad = v
+        if ready:
+            views = [b["views"][id(p)] for p in ready]
+            torch._foreach_copy_(views, [p.grad for p in ready])
+            for p, v in zip(ready, views):
+                p.grad = v
         b["ready"] = []
+        b["launched"] = True
+        assert b["index"] == self._next, "buckets go out in index order"
+        self._next += 1
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        _trace(f"launch bucket {b['index']} ({b['flat'].numel()} elements, {len(ready)} gradients packed)")
         self._works.append((dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True), b))
 
     def finish(self):
-        """Wait for every outstanding bucket, flush buckets whose parameters got no gradient this step."""
-        if self.world > 1:
-            for b in self.buckets:
-                if 0 < b["pending"] < b["count"]:
-                    # some parameters of this bucket were unused: their slots hold zeros
-                    self._launch(b)
+        """Launch the buckets that are not out yet, wait for all of them."""
+        if self.exchange:
+            _trace("finish enter")
+            while self._next < len(self.buckets):
+                self._launch(self.buckets[self._next])
             for w, b in self._works:
                 w.wait()
                 if not self._avg:
                     b["flat"].div_(self.world)
+            _trace(f"finish exit ({len(self._works)} buckets exchanged)")
         self._works.clear()
+        self._in_backward = False
+        self._next = 0
         for b in self.buckets:
             b["pending"] = b["count"]
+            b["launched"] = False
+            b["ready"] = []
 
     def zero_grad(self):
-        """Drop last step's gradients; with several ranks also clear the flat buckets (slots of parameters that
+        """Drop last step's gradients; with an exchange also clear the flat buckets (slots of parameters that
         receive no gradient must contribute zeros to the reduction)."""
-        if self.world > 1:
+        if self.exchange:
             for b in self.buckets:
                 b["flat"].zero_()
         for p in self.params:

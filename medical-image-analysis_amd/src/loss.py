@@ -116,3 +116,27 @@ def get_loss_function(task: str, num_classes: int = None, loss_type: str = "defa
             return IoULoss(num_classes=num_classes)
         return CombinedSegmentationLoss(num_classes=num_classes, weights=class_weights)
     raise ValueError(f"Unknown task: {task}")
+
+
+def calculate_class_weights(dataset, num_classes: int, task: str = "classification"):
+    """loss.py:163-196: inverse-frequency class weights, total / (num_classes * count[c]) as a float32 CPU tensor
+    (a class that never occurs gets inf, as in the reference). `dataset` yields dicts with 'label' (classification)
+    or 'mask' (segmentation; every pixel counts towards the total, values outside [0, num_classes) towards no class).
+    Host code: it walks a Python dataset once before training starts."""
+    if task not in ("classification", "segmentation"):
+        raise ValueError(f"Unknown task: {task}")
+    counts = torch.zeros(num_classes, dtype=torch.int64)
+    total = 0
+    for sample in dataset:
+        if task == "classification":
+            counts[int(sample["label"])] += 1
+            total += 1
+        else:
+            mask = torch.as_tensor(sample["mask"]).reshape(-1).long().cpu()
+            total += mask.numel()
+            inside = mask[(mask >= 0) & (mask < num_classes)]
+            counts += torch.bincount(inside, minlength=num_classes)
+    if task == "classification":
+        total = len(dataset)
+    # Python int over a float32 tensor, the reference's expression: torch forms reciprocal(x) * total
+    return int(total) / (num_classes * counts.to(torch.float32))

@@ -98,6 +98,32 @@ def test_cross_entropy_matches_torch():
     assert rel(logits.grad, ref_l.grad) < 1e-5
 
 
+def test_cross_entropy_ignored_and_invalid_labels():
+    """nn.CrossEntropyLoss semantics for labels that are not classes: -100 rows leave the mean (sum and divisor) and get
+    a zero gradient; a label >= n (a device assert in torch) is never used as an index: zero gradient row, NaN loss."""
+    logits = randn(4, 300, 4).cuda().requires_grad_(True)
+    lab = np.random.default_rng(5).integers(0, 4, 300)
+    lab[[0, 7, 130, 299]] = -100
+    labels = torch.from_numpy(lab).cuda()
+    loss = head_ops.CrossEntropyLoss()(logits, labels)
+    loss.backward()
+    ref_l = logits.detach().cpu().clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ref_l, labels.cpu())
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item()))
+    assert rel(logits.grad.cpu(), ref_l.grad) < 1e-5
+    assert float(logits.grad[[0, 7, 130, 299]].abs().sum()) == 0.0
+    bad = labels.clone()
+    bad[7], bad[9] = 4, -3
+    l2 = logits.detach().clone().requires_grad_(True)
+    loss2 = head_ops.CrossEntropyLoss()(l2, bad)
+    loss2.backward()
+    assert torch.isnan(loss2).item()
+    assert float(l2.grad[[7, 9]].abs().sum()) == 0.0 and torch.isfinite(l2.grad).all()
+    allign = torch.full((5,), -100, dtype=torch.int64, device="cuda")
+    assert torch.isnan(head_ops.CrossEntropyLoss()(randn(6, 5, 4).cuda(), allign)).item()   # 0/0, as in torch
+
+
 def test_dropout_statistics_and_determinism():
     """Train-mode dropout (p=0.2): kept fraction ~0.8, kept values scaled by 1/0.8, same mask in backward."""
     x = torch.ones(1 << 16, device="cuda", requires_grad=True)

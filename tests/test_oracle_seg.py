@@ -79,3 +79,24 @@ def test_segmentation_losses_match_reference_golden(tag):
         loss.backward()
         np.testing.assert_allclose(loss.item(), gold[name + ".loss"], rtol=1e-6, atol=1e-7, err_msg=name)
         np.testing.assert_allclose(z.grad.numpy(), gold[name + ".dlogits"], rtol=1e-5, atol=1e-9, err_msg=name)
+
+
+def test_calculate_class_weights_matches_reference():
+    """calculate_class_weights against the reference function's outputs (tests/golden/make_class_weights.py)."""
+    import os
+    import numpy as np
+    import torch
+    import mia_amd  # noqa: F401
+    from mia_amd.src.loss import calculate_class_weights
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "class_weights.npz"))
+    cls = [{"label": int(v)} for v in g["labels"]]
+    seg = [{"mask": torch.from_numpy(m)} for m in g["masks"]]
+    for n, key in ((4, "cls_w4"), (6, "cls_w6")):
+        w = calculate_class_weights(cls, n, "classification")
+        assert w.dtype == torch.float32
+        np.testing.assert_array_equal(w.numpy(), g[key])
+    for n, key in ((3, "seg_w3"), (2, "seg_w2")):
+        np.testing.assert_array_equal(calculate_class_weights(seg, n, "segmentation").numpy(), g[key])
+    import pytest
+    with pytest.raises(ValueError, match="Unknown task"):
+        calculate_class_weights(cls, 4, "detection")
