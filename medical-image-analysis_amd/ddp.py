@@ -47,6 +47,10 @@ class GradReducer:
         self._param_bucket = {}
         self._works = []
         self._avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        # gloo (CPU rehearsals of the multi-rank step, never production): the collectives run on host copies of the
+        # buckets. c10d's own handling of device tensors under gloo hung intermittently on this ROCm build with two
+        # processes sharing a GPU (inside dist.broadcast of a small tensor, and inside work.wait() of an all-reduce)
+        self._host_staged = dist.is_initialized() and dist.get_backend(group) == "gloo"
         self._in_backward = False
         cur, cur_bytes = [], 0
         for p in reversed(self.params):
@@ -85,7 +89,12 @@ class GradReducer:
             by_dtype.setdefault((t.dtype, t.device), []).append(t.data)
         for (dtype, device), tensors in by_dtype.items():
             flat = torch.cat([t.reshape(-1) for t in tensors])
-            dist.broadcast(flat, src, group=self.group)
+            if self._host_staged and flat.is_cuda:
+                host = flat.cpu()
+                dist.broadcast(host, src, group=self.group)
+                flat.copy_(host)
+            else:
+                dist.broadcast(flat, src, group=self.group)
             off = 0
             for t in tensors:
                 n = t.numel()
@@ -124,7 +133,13 @@ class GradReducer:
         self._next += 1
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         _trace(f"launch bucket {b['index']} ({b['flat'].numel()} elements, {len(ready)} gradients packed)")
-        self._works.append((dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True), b))
+        buf = b["flat"]
+        if self._host_staged and buf.is_cuda:
+            if "host" not in b:
+                b["host"] = torch.empty(buf.shape, dtype=buf.dtype, pin_memory=True)
+            buf = b["host"]
+            buf.copy_(b["flat"])        # blocking copy: the gradients packed above have been computed when it returns
+        self._works.append((dist.all_reduce(buf, op=op, group=self.group, async_op=True), b))
 
     def finish(self):
         """Launch the buckets that are not out yet, wait for all of them."""
@@ -134,6 +149,8 @@ class GradReducer:
                 self._launch(self.buckets[self._next])
             for w, b in self._works:
                 w.wait()
+                if self._host_staged and b["flat"].is_cuda:
+                    b["flat"].copy_(b["host"])
                 if not self._avg:
                     b["flat"].div_(self.world)
             _trace(f"finish exit ({len(self._works)} buckets exchanged)")

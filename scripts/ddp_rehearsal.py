@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--size", type=int, default=96)
     ap.add_argument("--stall", type=int, default=45)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--per-tensor-broadcast", action="store_true",
+                    help="broadcast every parameter and buffer with a collective of its own (the first version of "
+                         "broadcast_parameters) instead of one flat buffer per dtype")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -58,7 +61,14 @@ def main():
     phase("model built")
     reducer = GradReducer(model.parameters(), always_exchange=True)
     phase(f"{len(reducer.buckets)} buckets")
-    reducer.broadcast_parameters(model)
+    if args.per_tensor_broadcast:
+        tensors = list(model.parameters()) + list(model.buffers())
+        for i, t in enumerate(tensors):
+            dist.broadcast(t.data, 0)
+            if i % 100 == 0:
+                phase(f"broadcast tensor {i} of {len(tensors)} ({tuple(t.shape)}, {t.dtype})")
+    else:
+        reducer.broadcast_parameters(model)
     torch.cuda.synchronize()
     phase("broadcast done")
     opt = AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
@@ -80,10 +90,12 @@ def main():
         torch.cuda.synchronize()
         phase(f"step {step}: optimizer done, loss {loss.item():.4f}")
     cs = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
+    if backend != "nccl":
+        cs = cs.cpu()      # gloo: host tensors, so that the check does not depend on c10d's device-tensor path
     lo, hi = cs.clone(), cs.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-    ok = bool((lo == hi).item())
+    ok = bool((lo.cpu() == hi.cpu()).item())
     phase(f"replicas in sync: {ok}")
     faulthandler.cancel_dump_traceback_later()
     dist.destroy_process_group()
