@@ -28,6 +28,7 @@ FAMILIES = ["gemm_nt", "gemm_tn", "dwconv_fwd", "dwconv_bwd_data", "dwconv_bwd_w
 # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, scripts/pmc_traffic.sh), by kernel
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 TRAIN_GFLOP_PER_IMG = {"b3_cbam": 11.00, "b3_plain": 10.60}   # 3 x forward FLOPs at 300x300
+NBATCH = 4                 # resident synthetic batches the steps rotate over
 
 
 def phantom_batch(n, seed):
@@ -39,8 +40,9 @@ def phantom_batch(n, seed):
     return img * mask[None]
 
 
-def cpu_baseline(batch=8, steps=2, use_attention=True):
-    """The CPU oracle (plain PyTorch fp32 restatement) timed on the host cores: same step, bounded sample."""
+def cpu_baseline(batch=8, steps=5, warmup=2, use_attention=True):
+    """The CPU oracle (plain PyTorch fp32 restatement) timed on the host cores: same step, bounded sample
+    (median of `steps` steps after `warmup` untimed ones)."""
     from oracle.effnet_b3 import OracleFoundationModel
     torch.manual_seed(0)
     m = OracleFoundationModel({"synthetic": 4}, dropout=0.2, use_attention=use_attention).train()
@@ -52,14 +54,17 @@ def cpu_baseline(batch=8, steps=2, use_attention=True):
         opt.zero_grad()
         torch.nn.functional.cross_entropy(m(x, "classification", "synthetic"), y).backward()
         opt.step()
-    step()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(warmup):
         step()
-    dt = time.perf_counter() - t0
-    return {"value": round(batch * steps / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{steps} fp32 train steps of batch {batch} at 300x300 after 1 warm-up "
-                                      f"(oracle/effnet_b3.py, torch {torch.__version__} CPU)"}
+    times = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": round(batch / med, 2), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"median of {steps} fp32 train steps of batch {batch} at 300x300 after {warmup} "
+                                      f"warm-ups (oracle/effnet_b3.py, torch {torch.__version__} CPU)"}
 
 
 def main():
@@ -106,17 +111,25 @@ def main():
     reducer.broadcast_parameters(model)
     opt = AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
 
-    # synthetic MRI-shaped batch, preprocessed on the device by the resize+normalise kernel, resident in HBM
-    raw = torch.from_numpy(phantom_batch(args.batch, 1234 + rank)).to(dev)
-    x = PP.resize_normalize(raw, (300, 300))
-    y = torch.from_numpy(np.random.default_rng(99 + rank).integers(0, 4, args.batch)).to(dev)
+    # synthetic MRI-shaped batches, preprocessed on the device by the resize+normalise kernel, resident in HBM. The
+    # steps rotate over NBATCH different batches so that the timed steps keep back-propagating a real gradient (one
+    # fixed batch is memorised within the warm-up and the loss collapses to 0)
+    xs, ys = [], []
+    for i in range(NBATCH):
+        raw = torch.from_numpy(phantom_batch(args.batch, 1234 + 1000 * i + rank)).to(dev)
+        xs.append(PP.resize_normalize(raw, (300, 300)))
+        ys.append(torch.from_numpy(np.random.default_rng(99 + 1000 * i + rank).integers(0, 4, args.batch)).to(dev))
+    del raw
 
     criterion = CrossEntropyLoss()
+    counter = [0]
 
     def step():
+        i = counter[0] % NBATCH
+        counter[0] += 1
         reducer.zero_grad()
-        logits = model(x, "classification", "synthetic")
-        loss = criterion(logits, y)
+        logits = model(xs[i], "classification", "synthetic")
+        loss = criterion(logits, ys[i])
         loss.backward()
         reducer.finish()
         opt.step()
@@ -129,10 +142,13 @@ def main():
         torch.cuda.synchronize()
 
     # warm-up; the last warm-up step is event-timed per family to find the dominant one
+    first_loss = None
     for i in range(max(args.warmup, 1)):
         if i == max(args.warmup, 1) - 1:
             ops.KernelTimer.start(FAMILIES)
-        step()
+        l0 = step()
+        if first_loss is None:
+            first_loss = l0
     table = ops.KernelTimer.stop()
     dominant = max(table, key=lambda f: table[f][1]) if table else "gemm_nt"
 
@@ -149,6 +165,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_v = float(loss.item())
+    first_loss_v = float(first_loss.item())
     in_sync = None
     if world > 1:
         # replicas started identical and applied identical averaged gradients: their parameters must still agree
@@ -177,8 +194,8 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"EfficientNet-B3 {'+ CBAM/MHA head' if use_attention else '(plain head)'}, 4 classes, "
                                    f"300x300, per-GPU batch {args.batch} (global {world * args.batch}), train step = "
-                                   "fwd + CE + bwd + gradient all-reduce + AdamW; random-init weights, synthetic "
-                                   "MRI-shaped images resident in HBM",
+                                   f"fwd + CE + bwd + gradient all-reduce + AdamW; random-init weights, {NBATCH} synthetic "
+                                   "MRI-shaped batches resident in HBM, used in rotation",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "model_tflops_per_s": round(ips * TRAIN_GFLOP_PER_IMG[args.workload] / 1e3, 1)},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -186,8 +203,13 @@ def main():
                          "launches_per_step": launches / max(args.steps, 1),
                          "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2),
                          "algorithmic_bytes_per_launch": int(nbytes / max(launches, 1))},
-            "final_loss": round(loss_v, 4),
+            "first_loss": round(first_loss_v, 4), "final_loss": round(loss_v, 4),
         }
+        # every timed family of the last warm-up step against the HBM roof: the line checks itself
+        out["roofline"]["families"] = {
+            fam: {"launches": n, "ms": round(fms, 3), "GBps": round(fb / fms / 1e6, 1) if fms else 0.0,
+                  "frac": round(fb / fms / 1e6 / HBM_PEAK_GBS, 4) if fms else 0.0}
+            for fam, (n, fms, fb) in sorted(table.items(), key=lambda kv: -kv[1][1])}
         if in_sync is not None:
             out["replicas_in_sync"] = in_sync
         if args.kernel_table:

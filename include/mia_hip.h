@@ -39,11 +39,19 @@ int mia_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void*
                 int N, int K, const float* pscale, const float* pshift, int pro_act, const float* gate,
                 int rows_per_img, const float* bias, int epi_act, float* stats, int part_rows, void* stream);
 
-/* Weight gradient (autograd of the ops above, train.py:370): O[N,K] (fp32, leading dim ldo) += G[M,N]^T . pro(X)[M,K].
- * O must be zero-filled (or hold a gradient to accumulate into). */
+/* Weight gradient (autograd of the ops above, train.py:370): O[N,K] (fp32, leading dim ldo) = G[M,N]^T . pro(X)[M,K].
+ * The reduction over M is split across workgroups. With tickets != NULL the partial tiles go through the workspace
+ * ws and are added in a fixed order (bit-reproducible results, O is OVERWRITTEN and need not be initialised):
+ * ws holds at least mia_gemm_tn_ws_floats(...) floats (may be NULL when that is 0), tickets at least
+ * mia_gemm_tn_tickets(...) ints that are ZERO on entry and are left zero; launches that share tickets must not
+ * overlap (one tickets array per stream). With tickets == NULL the partials are added into O with float atomics:
+ * O must then be zero-filled (or hold a gradient to accumulate into) and the rounding varies from run to run. */
 int mia_gemm_tn(int dtype, const void* G, int ldg, const void* X, int ldx, float* O, int ldo, int M, int N, int K,
                 const float* pscale, const float* pshift, int pro_act, const float* gate, int rows_per_img,
-                void* stream);
+                float* ws, long long ws_floats, int* tickets, int n_tickets, void* stream);
+/* Sizes for the call above (has_prologue = pscale or gate given); return a count, not an error code (-1: bad shape). */
+long long mia_gemm_tn_ws_floats(int dtype, int M, int N, int K, int has_prologue);
+int mia_gemm_tn_tickets(int dtype, int M, int N, int K, int has_prologue);
 
 /* ---- depthwise k x k convolutions: timm conv_dw (k in {3,5}, stride in {1,2}, pad (k-1)/2, no bias) ----------
  * y[B,OH,OW,C] = dw(pro(x)[B,H,W,C]); pro = SiLU(x*pscale+pshift) when pscale != NULL; w is [C][k*k] fp32.
@@ -177,8 +185,11 @@ int mia_broadcast_rows(int dtype, const float* v, int B, int HW, int C, float mu
 /* x *= dropout mask (and zero where relu_ref <= 0): nn.Dropout after nn.ReLU, forward and backward. */
 int mia_dropout_f32(float* x, const float* relu_ref, long long n, float pdrop, unsigned long long seed,
                     const unsigned long long* seed_offset, void* stream);
-/* out[c] = sum_r x[r][c]: bias gradients. */
-int mia_colsum(int dtype, const void* x, long long R, int C, int ld, float* out, void* stream);
+/* out[c] = sum_r x[r][c]: bias gradients. ws (nullable): fp32 scratch of ws_floats floats; with min(128, R/64) * C
+ * floats the rows are summed by that many workgroups per 64 columns and folded in a fixed order (no float atomics);
+ * with less, by fewer (one without a workspace). */
+int mia_colsum(int dtype, const void* x, long long R, int C, int ld, float* out, float* ws, long long ws_floats,
+               void* stream);
 /* nn.CrossEntropyLoss (src/loss.py:147; train.py:352): mean loss and d loss / d logits (zero padded to ldd columns).
  * A label of -100 (the default ignore_index) drops its row from the sum and the divisor; any other label outside
  * [0, n) (a device-side assert in torch) gives a zero gradient row and a NaN loss, and is never used as an index. */

@@ -27,9 +27,9 @@ def parse_header(path=HEADER):
     text = open(path).read()
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
     protos = {}
-    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(mia_\w+)\s*\(([^)]*)\)\s*;", text):
+    for m in re.finditer(r"(const\s+char\s*\*|long\s+long|int)\s+(mia_\w+)\s*\(([^)]*)\)\s*;", text):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
-        restype = ctypes.c_char_p if "char" in ret else ctypes.c_int
+        restype = ctypes.c_char_p if "char" in ret else ctypes.c_longlong if "long" in ret else ctypes.c_int
         argtypes = []
         if args and args != "void":
             for a in args.split(","):
@@ -59,7 +59,7 @@ class _Lib:
             fn = getattr(self._dll, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
-            if restype is ctypes.c_int and name not in ("mia_version", "mia_cbam_ws_floats"):
+            if restype is ctypes.c_int and name not in ("mia_version", "mia_cbam_ws_floats", "mia_gemm_tn_tickets"):
                 setattr(self, name, self._checked(name, fn))
             else:
                 setattr(self, name, fn)

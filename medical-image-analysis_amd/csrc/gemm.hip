@@ -623,7 +623,76 @@ struct GemmTNParams {
     int rows_per_img;
     int pro_act;
     int chunks_per_split;
+    // deterministic split reduction (ws != null): every split stores its partial tile into its own slot of ws, the
+    // last split of a group to arrive (ticket counter) adds the group's slots in split order, the last group to
+    // finish adds the group sums in group order and writes O. The order of the additions is fixed, so the result is
+    // bit-reproducible whatever order the workgroups run in; no zero-filled output, no float atomics.
+    int det;        // 1: deterministic path (O overwritten), 0: float atomics into O
+    float* ws;      // unused when splits == 1
+    unsigned ws_bytes;
+    int* tickets;   // [tiles][ngroups + 1], zero on entry, left zero on exit
+    int splits, group, ngroups;
+    int slot;       // floats per slot = rows x cols of the largest tile
 };
+
+// The partial tiles of the split weight-gradient reduction travel between workgroups (possibly on different XCDs,
+// whose L2 caches are not coherent with each other) inside one kernel. They are written and read with agent-scope
+// cache policy (sc1: stores write through to memory, loads do not use a stale line of the local L2), the way the
+// compiler implements agent-scope atomic accesses; with that, waiting for the stores to complete (vmcnt) before taking
+// a ticket is all the release a producer needs. A device-wide fence would also do, but it writes back the whole L2 of
+// the XCD every time: measured 2.5x the kernel time with a few hundred workgroups each fencing once.
+#define MIA_CPOL_SC1 16
+__device__ __forceinline__ void ws_store1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, byte_off, 0, MIA_CPOL_SC1);
+}
+__device__ __forceinline__ f32x4 ws_load4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, MIA_CPOL_SC1);
+    return f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+__device__ __forceinline__ void ws_store4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, f32x4 a) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u v = {__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3])};
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, MIA_CPOL_SC1);
+}
+
+// Sum of `count` partial tiles (slot z at float offset src + z*slot of the workspace, cnt4 float4 each), added in slot
+// order, by one workgroup of 256 threads. Eight independent float4 chains per thread and pass keep enough loads in
+// flight for a single workgroup to stream the slots; the order of the additions per output element does not depend on
+// the unrolling. TO_O: write element e of the sum to out (= O's tile) at (e / kw, e % kw) with row stride ldo, else
+// to the workspace at float offset dst + 4*e.
+template <bool TO_O>
+__device__ __forceinline__ void tn_reduce_slots(__amdgpu_buffer_rsrc_t rs, unsigned src, unsigned slot, int count,
+                                                int cnt4, int kw, float* __restrict__ out, int ldo, unsigned dst,
+                                                int tid) {
+    constexpr int U = 8;
+    for (int e0 = tid; e0 < cnt4; e0 += 256 * U) {
+        f32x4 a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < count; ++z) {
+            const unsigned sz = (src + (unsigned)z * slot) * 4u;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * 256;
+                // past the tile: an offset beyond the descriptor returns zeros
+                a[u] += ws_load4(rs, e < cnt4 ? sz + (unsigned)e * 16u : MIA_BUF_OOB);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * 256;
+            if (e < cnt4) {
+                if (TO_O) {
+                    const int ln = (e * 4) / kw, lk = (e * 4) - ln * kw;
+                    *reinterpret_cast<float4*>(out + (size_t)ln * ldo + lk) = make_float4(a[u][0], a[u][1], a[u][2], a[u][3]);
+                } else {
+                    ws_store4(rs, (dst + (unsigned)e * 4u) * 4u, a[u]);
+                }
+            }
+        }
+    }
+}
 
 // LAYOUT: how the four waves share the 128x128 tile. 0: 2x2 waves of 64x64. 1: the k extent of the whole product
 // is <= 64 (narrow activations: 24..40 input channels): 4x1 waves of 32(n) x 64(k), so every wave has work and the
@@ -801,24 +870,142 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
     }
 
     const int lrow = (lane >> 4) * 4, lcol = lane & 15;
+    if (!p.det) {
+        // accumulate into O with float atomics (callers without a workspace; the order of the additions varies)
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            if (i < mt_cnt && j < nt_cnt) {
-                const int gk = k0 + wc * WK + j * 16 + lcol;
+            for (int j = 0; j < NT; ++j) {
+                if (i < mt_cnt && j < nt_cnt) {
+                    const int gk = k0 + wc * WK + j * 16 + lcol;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gn = n0 + wr * WN + i * 16 + lrow + r;
-                    if (gn < N && gk < K) atomicAdd(p.O + (size_t)gn * p.ldo + gk, acc[i][j][r]);
+                    for (int r = 0; r < 4; ++r) {
+                        const int gn = n0 + wr * WN + i * 16 + lrow + r;
+                        if (gn < N && gk < K) atomicAdd(p.O + (size_t)gn * p.ldo + gk, acc[i][j][r]);
+                    }
                 }
             }
+        return;
+    }
+    // ---- deterministic path ----
+    const int nh = N - n0 < BT ? N - n0 : BT, kw = K - k0 < BT ? K - k0 : BT;   // valid extent of this tile
+    const int S = p.splits;
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x, ntiles = gridDim.x * gridDim.y;
+    float* otile = p.O + (size_t)n0 * p.ldo + k0;
+    if (S == 1) {
+        // the reduction is not split: straight to O
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (i < mt_cnt && j < nt_cnt) {
+                    const int lk = wc * WK + j * 16 + lcol;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ln = wr * WN + i * 16 + lrow + r;
+                        if (ln < nh && lk < kw) otile[(size_t)ln * p.ldo + lk] = acc[i][j][r];
+                    }
+                }
+            }
+        return;
+    }
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.ws, p.ws_bytes);
+    const unsigned slot = (unsigned)p.slot;
+    {
+        const unsigned mine = ((unsigned)tile * S + blockIdx.z) * slot;   // float offset of this workgroup's slot
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (i < mt_cnt && j < nt_cnt) {
+                    const int lk = wc * WK + j * 16 + lcol;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ln = wr * WN + i * 16 + lrow + r;
+                        ws_store1(rsW, (ln < nh && lk < kw) ? (mine + (unsigned)(ln * kw + lk)) * 4u : MIA_BUF_OOB, acc[i][j][r]);
+                    }
+                }
+            }
+    }
+    __shared__ int s_last;
+    const int GS = p.group, NG = p.ngroups, g = blockIdx.z / GS;
+    const int gsize = (S - g * GS) < GS ? (S - g * GS) : GS;
+    int* tk = p.tickets + (size_t)tile * (NG + 1);
+    // every thread's partial stores have completed (workgroup-scope release = wait for the memory counters; the
+    // stores themselves are write-through) before thread 0 takes the ticket
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(tk + g, 1) == gsize - 1;
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) tk[g] = 0;   // every split of the group has arrived: the counter is ready for the next launch
+    const int cnt4 = nh * kw / 4;   // kw is a multiple of 4 (K is a multiple of the 16-byte vector)
+    {
+        const unsigned src = ((unsigned)tile * S + (unsigned)g * GS) * slot;
+        if (NG == 1) {
+            tn_reduce_slots<true>(rsW, src, slot, gsize, cnt4, kw, otile, p.ldo, 0u, tid);
+            return;
         }
+        tn_reduce_slots<false>(rsW, src, slot, gsize, cnt4, kw, nullptr, 0,
+                               ((unsigned)ntiles * S + (unsigned)tile * NG + g) * slot, tid);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(tk + NG, 1) == NG - 1;
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) tk[NG] = 0;
+    tn_reduce_slots<true>(rsW, ((unsigned)ntiles * S + (unsigned)tile * NG) * slot, slot, NG, cnt4, kw, otile, p.ldo, 0u,
+                          tid);
+}
+
+// How the reduction over M is split, shared by the launch and by the workspace query.
+struct TnPlan {
+    int chunks_per_split, splits, group, ngroups, tiles, slot;
+    long long ws_floats;
+    int n_tickets;
+};
+static TnPlan tn_plan(int dtype, int M, int N, int K, bool pro) {
+    TnPlan t;
+    const int BR = dtype == MIA_BF16 ? 64 : 32;
+    t.tiles = cdiv(N, 128) * cdiv(K, 128);
+    const long long chunks = ((long long)M + BR - 1) / BR;
+    // aim for ~512 blocks (two per CU), but keep splits long enough to amortise their partial-tile epilogue: at least
+    // 16 reduction chunks per split for the plain variant, 4 for the prologue variant, whose chunks carry the
+    // activation work and prefer the parallelism
+    const int min_chunks = pro ? 4 : 16;
+    long long splits = 512 / t.tiles;
+    if (splits < 1) splits = 1;
+    if (splits > (chunks + min_chunks - 1) / min_chunks) splits = (chunks + min_chunks - 1) / min_chunks;
+    if (splits < 1) splits = 1;
+    t.chunks_per_split = (int)((chunks + splits - 1) / splits);
+    t.splits = (int)((chunks + t.chunks_per_split - 1) / t.chunks_per_split);
+    // up to 32 partials are added by one workgroup; beyond that two levels of about sqrt(splits) each
+    t.group = t.splits;
+    if (t.splits > 32) {
+        t.group = 1;
+        while (t.group * t.group < t.splits) ++t.group;
+    }
+    t.ngroups = cdiv(t.splits, t.group);
+    t.slot = (N < 128 ? N : 128) * (K < 128 ? K : 128);
+    t.ws_floats = t.splits == 1 ? 0 : (long long)t.tiles * (t.splits + (t.ngroups > 1 ? t.ngroups : 0)) * t.slot;
+    t.n_tickets = t.tiles * (t.ngroups + 1);
+    return t;
+}
+
+extern "C" long long mia_gemm_tn_ws_floats(int dtype, int M, int N, int K, int has_prologue) {
+    if (M <= 0 || N <= 0 || K <= 0) return -1;
+    return tn_plan(dtype, M, N, K, has_prologue != 0).ws_floats;
+}
+extern "C" int mia_gemm_tn_tickets(int dtype, int M, int N, int K, int has_prologue) {
+    if (M <= 0 || N <= 0 || K <= 0) return -1;
+    return tn_plan(dtype, M, N, K, has_prologue != 0).n_tickets;
 }
 
 extern "C" int mia_gemm_tn(int dtype, const void* G, int ldg, const void* X, int ldx, float* O, int ldo, int M, int N,
                            int K, const float* pscale, const float* pshift, int pro_act, const float* gate,
-                           int rows_per_img, void* stream) {
+                           int rows_per_img, float* ws, long long ws_floats, int* tickets, int n_tickets,
+                           void* stream) {
     const int vec = dtype == MIA_BF16 ? 8 : 4;
     MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "mia_gemm_tn: bad dtype %d", dtype);
     MIA_CHECK_ARG(G && X && O, "mia_gemm_tn: null operand");
@@ -835,21 +1022,23 @@ extern "C" int mia_gemm_tn(int dtype, const void* G, int ldg, const void* X, int
     p.G = G; p.X = X; p.O = O; p.M = M; p.N = N; p.K = K; p.ldg = ldg; p.ldx = ldx; p.ldo = ldo;
     p.pscale = pscale; p.pshift = pshift; p.gate = gate; p.rows_per_img = rows_per_img > 0 ? rows_per_img : 1;
     p.pro_act = pro_act;
-    const int BR = dtype == MIA_BF16 ? 64 : 32;
-    const int tiles = cdiv(N, 128) * cdiv(K, 128);
-    const long long chunks = ((long long)M + BR - 1) / BR;
-    // aim for ~512 blocks (two per CU). Every split ends with one float atomic per output element, so short splits
-    // are dominated by that traffic: at least 16 reduction chunks per split for the plain variant (measured on the
-    // 1392x232 gradient at M = 12800: 23 splits 59 us, 12 splits 46 us), 4 for the prologue variant, whose chunks
-    // carry the activation work and prefer the parallelism
     const bool pro = pscale || gate;
-    const int min_chunks = pro ? 4 : 16;
-    long long splits = 512 / tiles;
-    if (splits < 1) splits = 1;
-    if (splits > (chunks + min_chunks - 1) / min_chunks) splits = (chunks + min_chunks - 1) / min_chunks;
-    if (splits < 1) splits = 1;
-    p.chunks_per_split = (int)((chunks + splits - 1) / splits);
-    splits = (chunks + p.chunks_per_split - 1) / p.chunks_per_split;
+    const TnPlan t = tn_plan(dtype, M, N, K, pro);
+    p.chunks_per_split = t.chunks_per_split;
+    p.det = 0; p.ws = nullptr; p.tickets = nullptr;
+    p.splits = t.splits; p.group = t.group; p.ngroups = t.ngroups; p.slot = t.slot;
+    if (tickets != nullptr) {
+        // deterministic mode: O is overwritten
+        MIA_CHECK_ARG(t.ws_floats == 0 || (ws != nullptr && ws_floats >= t.ws_floats),
+                      "mia_gemm_tn: workspace of %lld floats needed (mia_gemm_tn_ws_floats), %lld given", t.ws_floats,
+                      ws_floats);
+        MIA_CHECK_ARG(n_tickets >= t.n_tickets, "mia_gemm_tn: %d ticket words needed (mia_gemm_tn_tickets), %d given",
+                      t.n_tickets, n_tickets);
+        MIA_CHECK_ARG(ldo % 4 == 0 && ((uintptr_t)O % 16) == 0, "mia_gemm_tn: O must be 16-byte aligned with ldo %% 4 == 0");
+        MIA_CHECK_ARG(t.ws_floats * 4 < (1ll << 32), "mia_gemm_tn: workspace beyond 4 GiB");
+        p.det = 1; p.ws = ws; p.ws_bytes = (unsigned)(t.ws_floats * 4); p.tickets = tickets;
+    }
+    const long long splits = t.splits;
     dim3 grid(cdiv(N, 128), cdiv(K, 128), (unsigned)splits);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int layout = K <= 64 ? 1 : (N <= 64 ? 2 : 0);

@@ -785,10 +785,11 @@ __global__ __launch_bounds__(256) void dropout_f32_kernel(float* x, const float*
     }
 }
 
-// column sums of an [R, C] matrix (bias gradients). grid = (ceil(C/64), row_chunks); the row chunks add their
-// partial with one float atomic per column (out is zero-filled by the launcher).
+// column sums of an [R, C] matrix (bias gradients). grid = (ceil(C/64), row_chunks); every row chunk writes its
+// partial sums to its own row of `part` ([row_chunks][C]; the output itself with one chunk), and colsum_fold adds the
+// rows in order: no float atomics, so the result does not depend on the order the workgroups ran in.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* x, long long R, int C, int ld, float* out) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, long long R, int C, int ld, float* part) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
     const long long rows_per = (R + gridDim.y - 1) / gridDim.y;
@@ -800,7 +801,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, long long R, in
     red[w][threadIdx.x & 63] = s;
     __syncthreads();
     if (w == 0 && c < C)
-        atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+        part[(size_t)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* part, int chunks, int C, float* out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += part[(size_t)k * C + c];
+    out[c] = s;
 }
 
 // softmax cross-entropy, mean over the batch, with its gradient (d loss / d logits). One workgroup.
@@ -1134,18 +1142,22 @@ extern "C" int mia_dropout_f32(float* x, const float* relu_ref, long long n, flo
     return 0;
 }
 
-extern "C" int mia_colsum(int dtype, const void* x, long long R, int C, int ld, float* out, void* stream) {
+extern "C" int mia_colsum(int dtype, const void* x, long long R, int C, int ld, float* out, float* ws,
+                          long long ws_floats, void* stream) {
     MIA_CHECK_ARG(x && out && R > 0 && C > 0 && ld >= C, "mia_colsum: bad arguments");
-    hipError_t e = mia_zero_words(out, C, MIA_STREAM);
-    MIA_CHECK_ARG(e == hipSuccess, "mia_colsum: zero fill failed: %s", hipGetErrorString(e));
+    // as many row chunks (of at least 64 rows, at most 128 chunks) as the workspace has rows for
     long long chunks = R / 64;
-    if (chunks < 1) chunks = 1;
     if (chunks > 128) chunks = 128;
+    if (ws == nullptr || chunks > ws_floats / C) chunks = ws == nullptr ? 1 : ws_floats / C;
+    if (chunks < 1) chunks = 1;
+    float* part = chunks == 1 ? out : ws;
     dim3 grid(cdiv(C, 64), (unsigned)chunks);
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, MIA_STREAM, (const bf16_t*)x, R, C, ld, out);
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, MIA_STREAM, (const bf16_t*)x, R, C, ld, part);
     else
-        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, MIA_STREAM, (const float*)x, R, C, ld, out);
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, MIA_STREAM, (const float*)x, R, C, ld, part);
+    if (chunks > 1)
+        hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, MIA_STREAM, part, (int)chunks, C, out);
     MIA_CHECK_LAUNCH("mia_colsum");
     return 0;
 }

@@ -113,7 +113,7 @@ class GraphedTrainStep:
 
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
-        ops.ZeroPool.drop()
+        ops.Tickets.drop()
         ops.Replay.seed_off = self.words.data_ptr()
         optimizer.begin_capture(self.words.data_ptr() + 16, self.MAX_ROWS)
         try:
@@ -122,7 +122,7 @@ class GraphedTrainStep:
         finally:
             ops.Replay.seed_off = None
             self.rows = optimizer.end_capture()
-            ops.ZeroPool.drop()
+            ops.Tickets.drop()
 
         # ---- put everything back: neither the warm-up steps nor the capture count as training
         with torch.no_grad():

@@ -19,7 +19,10 @@ def _seed() -> int:
 def colsum(x2d):
     R, C = x2d.shape
     out = torch.empty((C,), dtype=torch.float32, device=x2d.device)
-    lib().mia_colsum(_DT[x2d.dtype], _p(x2d), R, C, x2d.stride(0), _p(out), _stream())
+    chunks = max(1, min(128, R // 64))
+    ws = torch.empty((chunks * C,), dtype=torch.float32, device=x2d.device) if chunks > 1 else None
+    lib().mia_colsum(_DT[x2d.dtype], _p(x2d), R, C, x2d.stride(0), _p(out), _p(ws), chunks * C if chunks > 1 else 0,
+                     _stream())
     return out
 
 

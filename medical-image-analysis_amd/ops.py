@@ -116,46 +116,42 @@ def gemm_nt(a2d, b, out2d=None, *, pscale=None, pshift=None, pro_act=ACT_NONE, g
     return out2d, part
 
 
-class ZeroPool:
-    """Zero-filled fp32 scratch handed out in slices. The weight-gradient GEMM accumulates into its output with
-    atomics, so every call needs a zeroed buffer; one 64 MiB fill per ~16 M gradient elements replaces one small fill
-    launch per weight (55 per B3 training step). A slice is never handed out twice; a chunk is freed by the allocator
-    once the gradients cut from it are gone. Chunks are tied to the (device, stream) they were filled on."""
-    CHUNK = 16 << 20   # floats
-    _chunks = {}       # (device index, stream id) -> [tensor, offset]
+class Tickets:
+    """Per-(device, stream) counter words of the deterministic split reductions (mia_gemm_tn): zero-filled once, every
+    launch leaves them zero again. One array per stream because launches that share counters must not overlap."""
+    WORDS = 1 << 15
+    _arrays = {}
 
     @classmethod
     def drop(cls):
-        """Forget the partly used chunks. Around a graph capture: slices cut during the capture must come from a
-        chunk whose fill is itself part of the graph, and none of the graph's memory may be handed out afterwards."""
-        cls._chunks.clear()
+        """Forget the arrays. Around a graph capture: an array first used during the capture lives in the graph's
+        private pool (its zero fill is part of the graph), and must not be handed to eager launches afterwards."""
+        cls._arrays.clear()
 
     @classmethod
-    def take(cls, rows: int, cols: int, device) -> torch.Tensor:
-        numel = rows * cols
-        n = (numel + 63) // 64 * 64   # keep every slice 256-byte aligned
-        if n > cls.CHUNK // 4:
-            return torch.zeros((rows, cols), dtype=torch.float32, device=device)
+    def get(cls, device) -> torch.Tensor:
         key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-        slot = cls._chunks.get(key)
-        if slot is None or slot[1] + n > cls.CHUNK:
-            slot = [torch.zeros((cls.CHUNK,), dtype=torch.float32, device=device), 0]
-            cls._chunks[key] = slot
-        out = slot[0][slot[1]:slot[1] + numel].view(rows, cols)
-        slot[1] += n
-        return out
+        t = cls._arrays.get(key)
+        if t is None:
+            t = torch.zeros((cls.WORDS,), dtype=torch.int32, device=device)
+            cls._arrays[key] = t
+        return t
 
 
-def gemm_tn(g2d, x2d, *, pscale=None, pshift=None, pro_act=ACT_NONE, gate=None, rows_per_img=0, out=None):
-    """out[N,K] (fp32) = g[M,N]^T @ pro(x)[M,K]."""
+def gemm_tn(g2d, x2d, *, pscale=None, pshift=None, pro_act=ACT_NONE, gate=None, rows_per_img=0):
+    """out[N,K] (fp32) = g[M,N]^T @ pro(x)[M,K]; the split reduction over M is added in a fixed order."""
     M, N = g2d.shape
     K = x2d.shape[1]
     assert x2d.shape[0] == M and g2d.dtype == x2d.dtype
     _require_cuda(g2d)
-    if out is None:
-        out = ZeroPool.take(N, K, g2d.device)
-    _launch("gemm_tn", (M * N + M * K) * g2d.element_size() + N * K * 4, lib().mia_gemm_tn, _DT[g2d.dtype], _p(g2d), g2d.stride(0), _p(x2d), x2d.stride(0), _p(out), out.stride(0), M, N, K,
-                      _p(pscale), _p(pshift), pro_act, _p(gate), rows_per_img, _stream())
+    dt = _DT[g2d.dtype]
+    pro = 1 if (pscale is not None or gate is not None) else 0
+    out = torch.empty((N, K), dtype=torch.float32, device=g2d.device)
+    nws = lib().mia_gemm_tn_ws_floats(dt, M, N, K, pro)
+    ws = torch.empty((nws,), dtype=torch.float32, device=g2d.device) if nws > 0 else None
+    tk = Tickets.get(g2d.device)
+    _launch("gemm_tn", (M * N + M * K) * g2d.element_size() + N * K * 4, lib().mia_gemm_tn, dt, _p(g2d), g2d.stride(0), _p(x2d), x2d.stride(0), _p(out), out.stride(0), M, N, K,
+                      _p(pscale), _p(pshift), pro_act, _p(gate), rows_per_img, _p(ws), nws, _p(tk), tk.numel(), _stream())
     return out
 
 
@@ -434,7 +430,7 @@ class StemFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         col, y0, st, gamma = ctx.saved_tensors
-        g = dout.contiguous().view(y0.shape).clone()
+        g = dout.contiguous().view(y0.shape)   # updated in place: the incoming gradient has no other reader
         M = y0.shape[0]
         part = bn_act_bwd_reduce(g, y0, st, ACT_SILU)
         coef = bn_finalize_bwd(part, M, gamma, st, ctx.training)
