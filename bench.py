@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--workload", default="b3_cbam", choices=["b3_cbam", "b3_plain"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fork", action="store_true", help="A/B switch: weight gradients on the main stream instead of the side stream")
     ap.add_argument("--kernel-table", action="store_true", help="also print a per-family timing table to stderr")
     args = ap.parse_args()
 
@@ -101,6 +102,8 @@ def main():
     from mia_amd.optim import AdamW
     from mia_amd.src.model import FoundationModel
     mia_amd.lib().mia_check_device()
+    if args.no_fork:
+        ops.Side.enabled = False
 
     torch.manual_seed(1234)
     use_attention = args.workload == "b3_cbam"

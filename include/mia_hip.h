@@ -40,18 +40,18 @@ int mia_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void*
                 int rows_per_img, const float* bias, int epi_act, float* stats, int part_rows, void* stream);
 
 /* Weight gradient (autograd of the ops above, train.py:370): O[N,K] (fp32, leading dim ldo) = G[M,N]^T . pro(X)[M,K].
- * The reduction over M is split across workgroups. With tickets != NULL the partial tiles go through the workspace
- * ws and are added in a fixed order (bit-reproducible results, O is OVERWRITTEN and need not be initialised):
- * ws holds at least mia_gemm_tn_ws_floats(...) floats (may be NULL when that is 0), tickets at least
- * mia_gemm_tn_tickets(...) ints that are ZERO on entry and are left zero; launches that share tickets must not
- * overlap (one tickets array per stream). With tickets == NULL the partials are added into O with float atomics:
- * O must then be zero-filled (or hold a gradient to accumulate into) and the rounding varies from run to run. */
+ * The reduction over M is split across workgroups. With a workspace (ws != NULL, at least
+ * mia_gemm_tn_ws_floats(...) floats; or ws == NULL and ws_floats < 0 when that count is 0) every split writes its
+ * partial tile to ws and a second kernel adds the partials in a fixed order: bit-reproducible results, O is
+ * OVERWRITTEN and need not be initialised. With ws == NULL and ws_floats == 0 the partials are added into O with
+ * float atomics: O must then be zero-filled (or hold a gradient to accumulate into) and the rounding varies from run
+ * to run. */
 int mia_gemm_tn(int dtype, const void* G, int ldg, const void* X, int ldx, float* O, int ldo, int M, int N, int K,
                 const float* pscale, const float* pshift, int pro_act, const float* gate, int rows_per_img,
-                float* ws, long long ws_floats, int* tickets, int n_tickets, void* stream);
-/* Sizes for the call above (has_prologue = pscale or gate given); return a count, not an error code (-1: bad shape). */
+                float* ws, long long ws_floats, void* stream);
+/* Workspace size in floats for the call above (has_prologue = pscale or gate given); a count, not an error code
+ * (-1: bad shape; 0: the product runs unsplit). */
 long long mia_gemm_tn_ws_floats(int dtype, int M, int N, int K, int has_prologue);
-int mia_gemm_tn_tickets(int dtype, int M, int N, int K, int has_prologue);
 
 /* ---- depthwise k x k convolutions: timm conv_dw (k in {3,5}, stride in {1,2}, pad (k-1)/2, no bias) ----------
  * y[B,OH,OW,C] = dw(pro(x)[B,H,W,C]); pro = SiLU(x*pscale+pshift) when pscale != NULL; w is [C][k*k] fp32.

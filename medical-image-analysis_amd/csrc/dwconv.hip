@@ -64,7 +64,7 @@ __device__ __forceinline__ void dw_epilogue_store(const DwParams& p, unsigned id
 
 // block-level reduction of per-thread (s, q) over the pixel-threads that share a channel vector
 __device__ __forceinline__ void dw_write_stats(const DwParams& p, float* red, int tid, int nvec, int npt, int c0,
-                                               int cbv, const f22& s, const f22& q) {
+                                               int cbv, const f22& s, const f22& q, int slot) {
     __syncthreads();
     red[tid * 8 + 0] = s.lo.x; red[tid * 8 + 1] = s.lo.y; red[tid * 8 + 2] = s.hi.x; red[tid * 8 + 3] = s.hi.y;
     red[tid * 8 + 4] = q.lo.x; red[tid * 8 + 5] = q.lo.y; red[tid * 8 + 6] = q.hi.x; red[tid * 8 + 7] = q.hi.y;
@@ -76,8 +76,8 @@ __device__ __forceinline__ void dw_write_stats(const DwParams& p, float* red, in
             a += red[(pt * nvec + cv) * 8 + e];
             b += red[(pt * nvec + cv) * 8 + 4 + e];
         }
-        p.stats[((size_t)blockIdx.x * 2 + 0) * p.C + c0 + tid] = a;
-        p.stats[((size_t)blockIdx.x * 2 + 1) * p.C + c0 + tid] = b;
+        p.stats[((size_t)slot * 2 + 0) * p.C + c0 + tid] = a;
+        p.stats[((size_t)slot * 2 + 1) * p.C + c0 + tid] = b;
     }
 }
 
@@ -220,7 +220,9 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
 
     const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
     const int tid = threadIdx.x;
-    const int c0 = blockIdx.y * CB;
+    int slot, cblk;
+    dw_decode_block(p, slot, cblk);
+    const int c0 = cblk * CB;
     const int cbv = (p.C - c0) < CB ? (p.C - c0) : CB;  // valid channels in this block
     const int nvec = CB / 4, npt = 256 / nvec;
     const int cv = tid % nvec, pt = tid / nvec;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
         dw_tile_fetch<T, DW_NV>(regs, x + (size_t)b * p.H * p.W * p.C, IHT, IWT, oh0 * S - PAD, ow0 * S - PAD, p.H, p.W,
                                 p.C, c, chan_ok, pt, npt);
     };
-    const TileWalk walk = make_tile_walk(total);
+    const TileWalk walk = make_tile_walk(total, slot, p.gx);
     if (walk.first < walk.count) fetch(walk.base + walk.first);
     for (int wi = walk.first; wi < walk.count; wi += walk.stride) {
         const int work = walk.base + wi;
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
             }
         }
     }
-    if (p.stats) dw_write_stats(p, red, tid, nvec, npt, c0, cbv, st_s, st_q);
+    if (p.stats) dw_write_stats(p, red, tid, nvec, npt, c0, cbv, st_s, st_q, slot);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -513,7 +515,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_s2_kernel(DwParams p) {
 
     const T* __restrict__ dy = reinterpret_cast<const T*>(p.x);
     const int tid = threadIdx.x;
-    const int c0 = blockIdx.y * CB;
+    int slot, cblk;
+    dw_decode_block(p, slot, cblk);
+    const int c0 = cblk * CB;
     const int cbv = (p.C - c0) < CB ? (p.C - c0) : CB;
     const int nvec = CB / 4, npt = 256 / nvec;
     const int cv = tid % nvec, pt = tid / nvec;
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_s2_kernel(DwParams p) {
         dw_tile_fetch<T, DW_NV>(regs, dy + (size_t)b * p.OH * p.OW * p.C, IHT, IWT, r0 - 1, q0 - 1, p.OH, p.OW, p.C, c,
                                 chan_ok, pt, npt);
     };
-    const TileWalk walk = make_tile_walk(total);
+    const TileWalk walk = make_tile_walk(total, slot, p.gx);
     if (walk.first < walk.count) fetch(walk.base + walk.first);
     for (int wi = walk.first; wi < walk.count; wi += walk.stride) {
         const int work = walk.base + wi;
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_s2_kernel(DwParams p) {
             }
         }
     }
-    if (p.stats) dw_write_stats(p, red, tid, nvec, npt, c0, cbv, st_s, st_q);
+    if (p.stats) dw_write_stats(p, red, tid, nvec, npt, c0, cbv, st_s, st_q, slot);
 }
 
 // weight gradient: dW[c][kh][kw] = sum_{b,oh,ow} dY[b,oh,ow,c] * pro(x)[b, oh*S+kh-PAD, ow*S+kw-PAD, c]
@@ -631,7 +635,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, cons
     const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
     const T* __restrict__ dy = reinterpret_cast<const T*>(dyv);
     const int tid = threadIdx.x;
-    const int c0 = blockIdx.y * CB;
+    int slot, cblk;
+    dw_decode_block(p, slot, cblk);
+    const int c0 = cblk * CB;
     const int cbv = (p.C - c0) < CB ? (p.C - c0) : CB;
     const int nvec = CB / 4;
     // staging map: (pixel-thread, channel vector)
@@ -668,7 +674,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, cons
         dw_tile_fetch<T, DW_NVD>(dregs, dy + (size_t)b * p.OH * p.OW * p.C, TH, TW, oh0, ow0, p.OH, p.OW, p.C,
                                  c0 + s_cv * 4, s_chan_ok, s_pt, s_npt);
     };
-    const TileWalk walk = make_tile_walk(total);
+    const TileWalk walk = make_tile_walk(total, slot, p.gx);
     if (walk.first < walk.count) fetch(walk.base + walk.first);
     for (int wi = walk.first; wi < walk.count; wi += walk.stride) {
         const int work = walk.base + wi;
@@ -711,7 +717,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, cons
             float a = 0.f;
             for (int q_ = 0; q_ < npt; ++q_) a += red[((q_ * K + khh) * nvec + v_) * 4 + e];
             // slab row of this workgroup: [gridDim.x][C][K*K]; one plain store per output, no contention
-            slab[((size_t)blockIdx.x * p.C + c0 + ch) * (K * K) + khh * K + kw] = a;
+            slab[((size_t)slot * p.C + c0 + ch) * (K * K) + khh * K + kw] = a;
         }
     }
 }
@@ -901,8 +907,11 @@ template <typename T, int K, int S, int PH>
 static void launch_tile(const DwParams& p, int grid_x, hipStream_t s) {
     const int IHT = (p.TH - 1) * S + K, IWT = (p.TW - 1) * S + K;
     const size_t lds = (size_t)K * K * p.CB * 4 + 256 * 8 * 4 + (size_t)IHT * IWT * p.CB * sizeof(T);
-    dim3 grid(grid_x, cdiv(p.C, p.CB));
-    hipLaunchKernelGGL((dwconv_tile_kernel<T, K, S, PH>), grid, dim3(256), lds, s, p);
+    // 1-D grid decoded by dw_decode_block: the channel blocks of one tile walker run on one XCD at about the same time
+    DwParams q = p;
+    q.gx = grid_x; q.ncb = cdiv(p.C, p.CB);
+    dim3 grid((unsigned)(q.gx * q.ncb));
+    hipLaunchKernelGGL((dwconv_tile_kernel<T, K, S, PH>), grid, dim3(256), lds, s, q);
 }
 
 template <typename T>
@@ -1053,6 +1062,7 @@ extern "C" int mia_dwconv_fwd(int dtype, const void* x, int B, int H, int W, int
     p.tiles_h = cdiv(p.OH, p.TH); p.tiles_w = cdiv(p.OW, p.TW);
     const int total = B * p.tiles_h * p.tiles_w;
     int gx = total < 8192 ? total : 8192;
+        if (gx >= 16) gx &= ~7;   // a multiple of eight: sibling channel blocks share an XCD (dw_decode_block)
     if (stats) {
         if (gx > part_rows) gx = part_rows;
         if (gx < part_rows) {  // rows no workgroup owns must still read as zero
@@ -1100,6 +1110,7 @@ extern "C" int mia_dwconv_bwd_data(int dtype, const void* dy, int B, int H, int 
         p.tiles_h = cdiv(p.OH, p.TH); p.tiles_w = cdiv(p.OW, p.TW);
         const int total = B * p.tiles_h * p.tiles_w;
         int gx = total < 8192 ? total : 8192;
+        if (gx >= 16) gx &= ~7;   // a multiple of eight: sibling channel blocks share an XCD (dw_decode_block)
         if (stats) {
             if (gx > part_rows) gx = part_rows;
             if (gx < part_rows) {
@@ -1116,6 +1127,7 @@ extern "C" int mia_dwconv_bwd_data(int dtype, const void* dy, int B, int H, int 
         p.tiles_h = cdiv(OH, p.TH); p.tiles_w = cdiv(OW, p.TW);
         const int total = B * p.tiles_h * p.tiles_w;
         int gx = total < 8192 ? total : 8192;
+        if (gx >= 16) gx &= ~7;   // a multiple of eight: sibling channel blocks share an XCD (dw_decode_block)
         if (stats) {
             if (gx > part_rows) gx = part_rows;
             if (gx < part_rows) {
@@ -1124,7 +1136,8 @@ extern "C" int mia_dwconv_bwd_data(int dtype, const void* dy, int B, int H, int 
             }
         }
         const size_t lds = (size_t)K * K * p.CB * 4 + 256 * 8 * 4 + (size_t)(p.TH + 2) * (p.TW + 2) * p.CB * elem;
-        dim3 grid(gx, cdiv(C, p.CB));
+        p.gx = gx; p.ncb = cdiv(C, p.CB);
+        dim3 grid((unsigned)(p.gx * p.ncb));
         if (dtype == MIA_BF16) {
             if (K == 3) hipLaunchKernelGGL((dwconv_bwd_data_s2_kernel<bf16_t, 3>), grid, dim3(256), lds, s, p);
             else hipLaunchKernelGGL((dwconv_bwd_data_s2_kernel<bf16_t, 5>), grid, dim3(256), lds, s, p);
@@ -1200,9 +1213,11 @@ extern "C" int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int
     if (gx > 256) gx = 256;
     if (gx > total) gx = total;
     if (gx > ws_floats / ((long long)C * K * K)) gx = ws_floats / ((long long)C * K * K);
+    if (gx >= 16) gx &= ~7ll;   // a multiple of eight lets dw_decode_block keep a walker's channel blocks on one XCD
     const int IHT = (p.TH - 1) * S + K, IWT = (p.TW - 1) * S + K;
     const size_t lds = 256 * 4 * 4 + ((size_t)IHT * IWT + (size_t)p.TH * p.TW) * p.CB * elem;
-    dim3 grid((unsigned)gx, ncb);
+    p.gx = (int)gx; p.ncb = ncb;
+    dim3 grid((unsigned)(gx * ncb));
 #define MIA_DWW(T_, K_, S_, PH_) \
     hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T_, K_, S_>), grid, dim3(256), lds, s, p, dy, ws)
     if (dtype == MIA_BF16) {

@@ -623,103 +623,93 @@ struct GemmTNParams {
     int rows_per_img;
     int pro_act;
     int chunks_per_split;
-    // deterministic split reduction (ws != null): every split stores its partial tile into its own slot of ws, the
-    // last split of a group to arrive (ticket counter) adds the group's slots in split order, the last group to
-    // finish adds the group sums in group order and writes O. The order of the additions is fixed, so the result is
-    // bit-reproducible whatever order the workgroups run in; no zero-filled output, no float atomics.
-    int det;        // 1: deterministic path (O overwritten), 0: float atomics into O
-    float* ws;      // unused when splits == 1
-    unsigned ws_bytes;
-    int* tickets;   // [tiles][ngroups + 1], zero on entry, left zero on exit
-    int splits, group, ngroups;
+    // deterministic split reduction: every split stores its partial tile into its own slot of ws, and a second
+    // kernel (tn_fold_kernel) adds the slots of each tile in split order and writes O. The order of the additions is
+    // fixed, so the result is bit-reproducible whatever order the workgroups ran in; no zero-filled output, no float
+    // atomics. The hand-over between the two kernels is a kernel boundary, the one ordering every GPU guarantees.
+    int det;        // 1: partial tiles to ws (O written directly when splits == 1), 0: float atomics into O
+    float* ws;      // [tiles][splits][slot], unused when splits == 1
+    int splits;
     int slot;       // floats per slot = rows x cols of the largest tile
 };
 
-// The partial tiles of the split weight-gradient reduction travel between workgroups (possibly on different XCDs,
-// whose L2 caches are not coherent with each other) inside one kernel. They are written and read with agent-scope
-// cache policy (sc1: stores write through to memory, loads do not use a stale line of the local L2), the way the
-// compiler implements agent-scope atomic accesses; with that, waiting for the stores to complete (vmcnt) before taking
-// a ticket is all the release a producer needs. A device-wide fence would also do, but it writes back the whole L2 of
-// the XCD every time: measured 2.5x the kernel time with a few hundred workgroups each fencing once.
-#define MIA_CPOL_SC1 16
-__device__ __forceinline__ void ws_store1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, byte_off, 0, MIA_CPOL_SC1);
-}
-__device__ __forceinline__ f32x4 ws_load4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
-    typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, MIA_CPOL_SC1);
-    return f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-}
-__device__ __forceinline__ void ws_store4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, f32x4 a) {
-    typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    const v4u v = {__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3])};
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, MIA_CPOL_SC1);
-}
-
-// Sum of `count` partial tiles (slot z at float offset src + z*slot of the workspace, cnt4 float4 each), added in slot
-// order, by one workgroup of 256 threads. Eight independent float4 chains per thread and pass keep enough loads in
-// flight for a single workgroup to stream the slots; the order of the additions per output element does not depend on
-// the unrolling. TO_O: write element e of the sum to out (= O's tile) at (e / kw, e % kw) with row stride ldo, else
-// to the workspace at float offset dst + 4*e.
-template <bool TO_O>
-__device__ __forceinline__ void tn_reduce_slots(__amdgpu_buffer_rsrc_t rs, unsigned src, unsigned slot, int count,
-                                                int cnt4, int kw, float* __restrict__ out, int ldo, unsigned dst,
-                                                int tid) {
-    constexpr int U = 8;
-    for (int e0 = tid; e0 < cnt4; e0 += 256 * U) {
-        f32x4 a[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < count; ++z) {
-            const unsigned sz = (src + (unsigned)z * slot) * 4u;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int e = e0 + u * 256;
-                // past the tile: an offset beyond the descriptor returns zeros
-                a[u] += ws_load4(rs, e < cnt4 ? sz + (unsigned)e * 16u : MIA_BUF_OOB);
-            }
+// Second kernel of the deterministic weight gradient: O tile = sum over the splits' partial tiles, in split order.
+// A workgroup owns 256/ZL float4 columns of one tile; its ZL "z-lanes" each add every ZL-th slot (strided, so all of
+// them stream at once), and the ZL partial sums are then added in lane order. The order of the additions depends only
+// on (splits, ZL), never on timing. grid = (column chunks, tiles).
+template <int ZL>
+__global__ __launch_bounds__(256) void tn_fold_kernel(const float* __restrict__ ws, int splits, int slot, int N, int K,
+                                                      int TN, int TK, int tiles_n, float* __restrict__ O, int ldo) {
+    constexpr int COLS = 256 / ZL;
+    __shared__ float4 red[ZL][COLS];
+    const int tile = blockIdx.y;
+    const int tn_i = tile % tiles_n, tk_i = tile / tiles_n;
+    const int n0 = tn_i * TN, k0 = tk_i * TK;
+    const int nh = N - n0 < TN ? N - n0 : TN, kw = K - k0 < TK ? K - k0 : TK;
+    const int cnt4 = nh * kw / 4;
+    const int col = threadIdx.x % COLS, zl = threadIdx.x / COLS;
+    const int e = blockIdx.x * COLS + col;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < cnt4) {
+        const float4* src = reinterpret_cast<const float4*>(ws + (size_t)tile * splits * slot) + e;
+        const size_t zstride = (size_t)slot / 4;
+#pragma unroll 4
+        for (int z = zl; z < splits; z += ZL) {
+            const float4 b = src[(size_t)z * zstride];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
+    }
+    if (ZL > 1) {
+        red[zl][col] = a;
+        __syncthreads();
+        if (zl != 0) return;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int e = e0 + u * 256;
-            if (e < cnt4) {
-                if (TO_O) {
-                    const int ln = (e * 4) / kw, lk = (e * 4) - ln * kw;
-                    *reinterpret_cast<float4*>(out + (size_t)ln * ldo + lk) = make_float4(a[u][0], a[u][1], a[u][2], a[u][3]);
-                } else {
-                    ws_store4(rs, (dst + (unsigned)e * 4u) * 4u, a[u]);
-                }
-            }
+        for (int z = 1; z < ZL; ++z) {
+            const float4 b = red[z][col];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
+    }
+    if (e < cnt4) {
+        const int ln = (e * 4) / kw, lk = (e * 4) - ln * kw;
+        *reinterpret_cast<float4*>(O + (size_t)(n0 + ln) * ldo + k0 + lk) = a;
     }
 }
 
-// LAYOUT: how the four waves share the 128x128 tile. 0: 2x2 waves of 64x64. 1: the k extent of the whole product
-// is <= 64 (narrow activations: 24..40 input channels): 4x1 waves of 32(n) x 64(k), so every wave has work and the
-// accumulators halve. 2: the n extent is <= 64: 1x4 waves of 64(n) x 32(k).
-template <typename T, bool PRO, int LAYOUT>
+// Output tile TN (columns of G = rows of O) x TK (columns of X), shared by 4 waves laid out WR (along n) x WC (along
+// k). The tile extents on offer follow the EfficientNet-B3 channel counts, so that the narrow side of a weight matrix
+// (24..384 channels) is ONE tile wherever it fits: the wide operand is then streamed once instead of once per tile of
+// the narrow side, and there are fewer, fuller partial tiles to reduce.
+//   128x128 (2x2 waves)                                general
+//   128x64  (4x1)   K <= 64                            expansion weights of the first stages (24..48 input channels)
+//   64x128  (1x4)   N <= 64                            projection weights onto 24..48 channels
+//   144x128 (1x4)   64 < N <= 144, K > N               the 136-channel projections
+//   128x144 (4x1)   64 < K <= 144, N > K               the 136-channel expansions
+// (240- and 192-wide tiles for the 232- and 384-channel layers were measured too: their 30- and 24-fragment wave
+// tiles need more than 256 registers, which leaves one wave per SIMD, and at M = 12800 they ran 1.3-1.6x slower.)
+template <typename T, bool PRO, int TN, int TK, int WR>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
     using M_ = Mma<T>;
     using V_ = Vec16<T>;
-    constexpr int BT = 128;          // output tile edge (n and k)
     constexpr int BR = M_::BK;       // reduction rows per stage
     constexpr int VEC = V_::N;
-    constexpr int LD = BT + VEC;     // LDS row stride, elements
-    constexpr int CH = BR * (BT / VEC) / 256;  // 16-byte chunks per thread and operand at full tile width
-    constexpr int WR = LAYOUT == 1 ? 4 : (LAYOUT == 2 ? 1 : 2), WC = 4 / WR;   // waves along n, along k
-    constexpr int WN = (LAYOUT == 2 ? 64 : 128) / WR, WK = (LAYOUT == 1 ? 64 : 128) / WC;   // wave tile
+    constexpr int LDG = TN + VEC, LDX = TK + VEC;     // LDS row strides, elements
+    constexpr int CHG = (BR * (TN / VEC) + 255) / 256;  // 16-byte chunks per thread at full tile width
+    constexpr int CHX = (BR * (TK / VEC) + 255) / 256;
+    constexpr int WC = 4 / WR;
+    constexpr int WN = TN / WR, WK = TK / WC;   // wave tile
     constexpr int MT = WN / 16, NT = WK / 16;
+    static_assert(WN % 16 == 0 && WK % 16 == 0 && TN % VEC == 0 && TK % VEC == 0, "tile shape");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* Gs = reinterpret_cast<T*>(smem);  // [BR][LD]
-    T* Xs = Gs + BR * LD;                // [BR][LD]
-    float* ssm = reinterpret_cast<float*>(Xs + BR * LD);  // [2][BT] prologue scale, shift of this k tile
+    T* Gs = reinterpret_cast<T*>(smem);  // [BR][LDG]
+    T* Xs = Gs + BR * LDG;               // [BR][LDX]
+    float* ssm = reinterpret_cast<float*>(Xs + BR * LDX);  // [2][TK] prologue scale, shift of this k tile
 
     const T* __restrict__ G = reinterpret_cast<const T*>(p.G);
     const T* __restrict__ X = reinterpret_cast<const T*>(p.X);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
-    const int n0 = blockIdx.x * BT, k0 = blockIdx.y * BT;
+    const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
     const int M = p.M, N = p.N, K = p.K;
     const bool has_pro = PRO && p.pscale != nullptr;
     const bool has_gate = PRO && p.gate != nullptr;
@@ -737,19 +727,23 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
 
     // The (row, 16-byte chunk) items of a stage are dealt to the threads over the VALID width of the tile, so a
     // narrow operand (24 or 40 channels) still keeps every thread loading and activating.
-    const int cprg = ((N - n0 < BT ? N - n0 : BT) + VEC - 1) / VEC;
-    const int cprx = ((K - k0 < BT ? K - k0 : BT) + VEC - 1) / VEC;
-    int grow[CH], gcol[CH], xrow[CH], xcol[CH];
+    const int cprg = ((N - n0 < TN ? N - n0 : TN) + VEC - 1) / VEC;
+    const int cprx = ((K - k0 < TK ? K - k0 : TK) + VEC - 1) / VEC;
+    int grow[CHG], gcol[CHG], xrow[CHX], xcol[CHX];
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
+    for (int i = 0; i < CHG; ++i) {
         const int idx = tid + i * 256;
         grow[i] = idx / cprg; gcol[i] = (idx - grow[i] * cprg) * VEC;
+    }
+#pragma unroll
+    for (int i = 0; i < CHX; ++i) {
+        const int idx = tid + i * 256;
         xrow[i] = idx / cprx; xcol[i] = (idx - xrow[i] * cprx) * VEC;
     }
-    if (PRO && has_pro && tid < BT) {
+    if (PRO && has_pro && tid < TK) {
         const bool in = k0 + tid < K;
         ssm[tid] = in ? p.pscale[k0 + tid] : 1.f;
-        ssm[BT + tid] = in ? p.pshift[k0 + tid] : 0.f;
+        ssm[TK + tid] = in ? p.pshift[k0 + tid] : 0.f;
     }
 
     const long long chunk_begin = (long long)blockIdx.z * p.chunks_per_split;
@@ -757,14 +751,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
     const long long total_chunks = ((long long)M + BR - 1) / BR;
     if (chunk_end > total_chunks) chunk_end = total_chunks;
 
-    raw16 rg[CH], rx[CH];
-    float pg[PRO ? CH : 1][PRO ? VEC : 1];
+    raw16 rg[CHG], rx[CHX];
+    float pg[PRO ? CHX : 1][PRO ? VEC : 1];
     // element offsets of this thread's chunks inside a stage (the API bounds operands to < 2^31 elements)
-    unsigned goff[CH], xoff[CH];
-    int ximg[PRO ? CH : 1], xrem[PRO ? CH : 1];  // image index and row-in-image of each X chunk row, kept incrementally
+    unsigned goff[CHG], xoff[CHX];
+    int ximg[PRO ? CHX : 1], xrem[PRO ? CHX : 1];  // image index and row-in-image of each X chunk row, kept incrementally
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        goff[i] = (unsigned)(grow[i] * p.ldg + gcol[i]);
+    for (int i = 0; i < CHG; ++i) goff[i] = (unsigned)(grow[i] * p.ldg + gcol[i]);
+#pragma unroll
+    for (int i = 0; i < CHX; ++i) {
         xoff[i] = (unsigned)(xrow[i] * p.ldx + xcol[i]);
         if constexpr (PRO) {
             const long long mf = chunk_begin * BR + xrow[i];
@@ -778,10 +773,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
         const T* gp = G + (size_t)m0 * p.ldg + n0;
         const T* xp = X + (size_t)m0 * p.ldx + k0;
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
+        for (int i = 0; i < CHG; ++i) {
             rg[i] = make_uint4(0, 0, 0, 0);
-            rx[i] = make_uint4(0, 0, 0, 0);
             if (grow[i] < BR && m0 + grow[i] < M) rg[i] = *reinterpret_cast<const raw16*>(gp + goff[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < CHX; ++i) {
+            rx[i] = make_uint4(0, 0, 0, 0);
             if (xrow[i] < BR && m0 + xrow[i] < M) {
                 rx[i] = *reinterpret_cast<const raw16*>(xp + xoff[i]);
                 if constexpr (PRO) if (has_gate) {
@@ -804,14 +802,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
         const long long m0 = ch * BR;
         if constexpr (PRO) if (has_pro || has_gate) {
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
+            for (int i = 0; i < CHX; ++i) {
                 if (xrow[i] < BR && m0 + xrow[i] < M) {
                     float sc[VEC], sh[VEC];
                     if (has_pro) {
 #pragma unroll
                         for (int e = 0; e < VEC; e += 4) {
                             const float4 a4 = *reinterpret_cast<const float4*>(ssm + xcol[i] + e);
-                            const float4 b4 = *reinterpret_cast<const float4*>(ssm + BT + xcol[i] + e);
+                            const float4 b4 = *reinterpret_cast<const float4*>(ssm + TK + xcol[i] + e);
                             sc[e] = a4.x; sc[e + 1] = a4.y; sc[e + 2] = a4.z; sc[e + 3] = a4.w;
                             sh[e] = b4.x; sh[e + 1] = b4.y; sh[e + 2] = b4.z; sh[e + 3] = b4.w;
                         }
@@ -821,10 +819,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            if (grow[i] < BR) *reinterpret_cast<raw16*>(Gs + grow[i] * LD + gcol[i]) = rg[i];
-            if (xrow[i] < BR) *reinterpret_cast<raw16*>(Xs + xrow[i] * LD + xcol[i]) = rx[i];
-        }
+        for (int i = 0; i < CHG; ++i)
+            if (grow[i] < BR) *reinterpret_cast<raw16*>(Gs + grow[i] * LDG + gcol[i]) = rg[i];
+#pragma unroll
+        for (int i = 0; i < CHX; ++i)
+            if (xrow[i] < BR) *reinterpret_cast<raw16*>(Xs + xrow[i] * LDX + xcol[i]) = rx[i];
     };
 
     if (chunk_begin < chunk_end) prefetch(chunk_begin);
@@ -833,38 +832,52 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
         commit(ch);
         __syncthreads();
         if (ch + 1 < chunk_end) prefetch(ch + 1);  // in flight during the MFMAs below
+        // The shorter side of the wave tile is held in registers per reduction step, the longer side is read one
+        // fragment at a time (a 15-fragment side kept whole would cost 60 registers).
         if (mt_cnt == MT && nt_cnt == NT) {
             // full wave tile: no per-MFMA tests (left in, each compiles to a scalar branch around its MFMA and the
             // branches cost more than the MFMAs)
 #pragma unroll
             for (int kk = 0; kk < BR / M_::KSTEP; ++kk) {
-                typename M_::Frag a[MT], b[NT];
+                if constexpr (MT <= NT) {
+                    typename M_::Frag a[MT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    a[i] = M_::load_t(Gs + kk * M_::KSTEP * LD + wr * WN + i * 16, LD, lane);
+                    for (int i = 0; i < MT; ++i)
+                        a[i] = M_::load_t(Gs + kk * M_::KSTEP * LDG + wr * WN + i * 16, LDG, lane);
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    b[j] = M_::load_t(Xs + kk * M_::KSTEP * LD + wc * WK + j * 16, LD, lane);
+                    for (int j = 0; j < NT; ++j) {
+                        const typename M_::Frag b = M_::load_t(Xs + kk * M_::KSTEP * LDX + wc * WK + j * 16, LDX, lane);
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                        for (int i = 0; i < MT; ++i) acc[i][j] = M_::mma(a[i], b, acc[i][j]);
+                    }
+                } else {
+                    typename M_::Frag b[NT];
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]);
+                    for (int j = 0; j < NT; ++j)
+                        b[j] = M_::load_t(Xs + kk * M_::KSTEP * LDX + wc * WK + j * 16, LDX, lane);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const typename M_::Frag a = M_::load_t(Gs + kk * M_::KSTEP * LDG + wr * WN + i * 16, LDG, lane);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[i][j] = M_::mma(a, b[j], acc[i][j]);
+                    }
+                }
             }
         } else if (mt_cnt > 0 && nt_cnt > 0) {
 #pragma unroll
             for (int kk = 0; kk < BR / M_::KSTEP; ++kk) {
-                typename M_::Frag a[MT], b[NT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    a[i] = M_::load_t(Gs + kk * M_::KSTEP * LD + wr * WN + i * 16, LD, lane);
+                for (int i = 0; i < MT; ++i) {
+                    if (i < mt_cnt) {
+                        const typename M_::Frag a = M_::load_t(Gs + kk * M_::KSTEP * LDG + wr * WN + i * 16, LDG, lane);
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    b[j] = M_::load_t(Xs + kk * M_::KSTEP * LD + wc * WK + j * 16, LD, lane);
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        if (i < mt_cnt && j < nt_cnt) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]);
+                        for (int j = 0; j < NT; ++j)
+                            if (j < nt_cnt) {
+                                const typename M_::Frag b = M_::load_t(Xs + kk * M_::KSTEP * LDX + wc * WK + j * 16, LDX, lane);
+                                acc[i][j] = M_::mma(a, b, acc[i][j]);
+                            }
+                    }
+                }
             }
         }
     }
@@ -887,88 +900,52 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
             }
         return;
     }
-    // ---- deterministic path ----
-    const int nh = N - n0 < BT ? N - n0 : BT, kw = K - k0 < BT ? K - k0 : BT;   // valid extent of this tile
+    // ---- deterministic path: this split's partial tile to its slot (or straight to O when there is one split) ----
+    const int nh = N - n0 < TN ? N - n0 : TN, kw = K - k0 < TK ? K - k0 : TK;   // valid extent of this tile
     const int S = p.splits;
-    const int tile = blockIdx.y * gridDim.x + blockIdx.x, ntiles = gridDim.x * gridDim.y;
-    float* otile = p.O + (size_t)n0 * p.ldo + k0;
-    if (S == 1) {
-        // the reduction is not split: straight to O
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+    float* dst = S == 1 ? p.O + (size_t)n0 * p.ldo + k0 : p.ws + ((size_t)tile * S + blockIdx.z) * p.slot;
+    const int dld = S == 1 ? p.ldo : kw;
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (i < mt_cnt && j < nt_cnt) {
-                    const int lk = wc * WK + j * 16 + lcol;
+        for (int j = 0; j < NT; ++j) {
+            if (i < mt_cnt && j < nt_cnt) {
+                const int lk = wc * WK + j * 16 + lcol;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ln = wr * WN + i * 16 + lrow + r;
-                        if (ln < nh && lk < kw) otile[(size_t)ln * p.ldo + lk] = acc[i][j][r];
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const int ln = wr * WN + i * 16 + lrow + r;
+                    if (ln < nh && lk < kw) dst[(size_t)ln * dld + lk] = acc[i][j][r];
                 }
             }
-        return;
-    }
-    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.ws, p.ws_bytes);
-    const unsigned slot = (unsigned)p.slot;
-    {
-        const unsigned mine = ((unsigned)tile * S + blockIdx.z) * slot;   // float offset of this workgroup's slot
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (i < mt_cnt && j < nt_cnt) {
-                    const int lk = wc * WK + j * 16 + lcol;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ln = wr * WN + i * 16 + lrow + r;
-                        ws_store1(rsW, (ln < nh && lk < kw) ? (mine + (unsigned)(ln * kw + lk)) * 4u : MIA_BUF_OOB, acc[i][j][r]);
-                    }
-                }
-            }
-    }
-    __shared__ int s_last;
-    const int GS = p.group, NG = p.ngroups, g = blockIdx.z / GS;
-    const int gsize = (S - g * GS) < GS ? (S - g * GS) : GS;
-    int* tk = p.tickets + (size_t)tile * (NG + 1);
-    // every thread's partial stores have completed (workgroup-scope release = wait for the memory counters; the
-    // stores themselves are write-through) before thread 0 takes the ticket
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(tk + g, 1) == gsize - 1;
-    __syncthreads();
-    if (!s_last) return;
-    if (tid == 0) tk[g] = 0;   // every split of the group has arrived: the counter is ready for the next launch
-    const int cnt4 = nh * kw / 4;   // kw is a multiple of 4 (K is a multiple of the 16-byte vector)
-    {
-        const unsigned src = ((unsigned)tile * S + (unsigned)g * GS) * slot;
-        if (NG == 1) {
-            tn_reduce_slots<true>(rsW, src, slot, gsize, cnt4, kw, otile, p.ldo, 0u, tid);
-            return;
         }
-        tn_reduce_slots<false>(rsW, src, slot, gsize, cnt4, kw, nullptr, 0,
-                               ((unsigned)ntiles * S + (unsigned)tile * NG + g) * slot, tid);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(tk + NG, 1) == NG - 1;
-    __syncthreads();
-    if (!s_last) return;
-    if (tid == 0) tk[NG] = 0;
-    tn_reduce_slots<true>(rsW, ((unsigned)ntiles * S + (unsigned)tile * NG) * slot, slot, NG, cnt4, kw, otile, p.ldo, 0u,
-                          tid);
+}
+
+// The tile extents for a product (see gemm_tn_kernel): index into TN_SHAPES.
+struct TnShape { int tn, tk, wr; };
+static const TnShape TN_SHAPES[] = {{128, 128, 2}, {128, 64, 4}, {64, 128, 1}, {144, 128, 1}, {128, 144, 4}};
+static int tn_pick_shape(int dtype, int N, int K) {
+    if (K <= 64) return 1;
+    if (N <= 64) return 2;
+    if (dtype != MIA_BF16) return 0;
+    // the narrow side in one tile where a shape fits it; the other side stays 128 wide
+    if (N <= K && N > 128 && N <= 144) return 3;
+    if (K < N && K > 128 && K <= 144) return 4;
+    return 0;
 }
 
 // How the reduction over M is split, shared by the launch and by the workspace query.
 struct TnPlan {
-    int chunks_per_split, splits, group, ngroups, tiles, slot;
+    int shape;   // index into TN_SHAPES
+    int chunks_per_split, splits, tiles, slot;
     long long ws_floats;
-    int n_tickets;
 };
 static TnPlan tn_plan(int dtype, int M, int N, int K, bool pro) {
     TnPlan t;
     const int BR = dtype == MIA_BF16 ? 64 : 32;
-    t.tiles = cdiv(N, 128) * cdiv(K, 128);
+    t.shape = tn_pick_shape(dtype, N, K);
+    const int tn = TN_SHAPES[t.shape].tn, tk = TN_SHAPES[t.shape].tk;
+    t.tiles = cdiv(N, tn) * cdiv(K, tk);
     const long long chunks = ((long long)M + BR - 1) / BR;
     // aim for ~512 blocks (two per CU), but keep splits long enough to amortise their partial-tile epilogue: at least
     // 16 reduction chunks per split for the plain variant, 4 for the prologue variant, whose chunks carry the
@@ -980,16 +957,8 @@ static TnPlan tn_plan(int dtype, int M, int N, int K, bool pro) {
     if (splits < 1) splits = 1;
     t.chunks_per_split = (int)((chunks + splits - 1) / splits);
     t.splits = (int)((chunks + t.chunks_per_split - 1) / t.chunks_per_split);
-    // up to 32 partials are added by one workgroup; beyond that two levels of about sqrt(splits) each
-    t.group = t.splits;
-    if (t.splits > 32) {
-        t.group = 1;
-        while (t.group * t.group < t.splits) ++t.group;
-    }
-    t.ngroups = cdiv(t.splits, t.group);
-    t.slot = (N < 128 ? N : 128) * (K < 128 ? K : 128);
-    t.ws_floats = t.splits == 1 ? 0 : (long long)t.tiles * (t.splits + (t.ngroups > 1 ? t.ngroups : 0)) * t.slot;
-    t.n_tickets = t.tiles * (t.ngroups + 1);
+    t.slot = (N < tn ? N : tn) * (K < tk ? K : tk);
+    t.ws_floats = t.splits == 1 ? 0 : (long long)t.tiles * t.splits * t.slot;
     return t;
 }
 
@@ -997,15 +966,10 @@ extern "C" long long mia_gemm_tn_ws_floats(int dtype, int M, int N, int K, int h
     if (M <= 0 || N <= 0 || K <= 0) return -1;
     return tn_plan(dtype, M, N, K, has_prologue != 0).ws_floats;
 }
-extern "C" int mia_gemm_tn_tickets(int dtype, int M, int N, int K, int has_prologue) {
-    if (M <= 0 || N <= 0 || K <= 0) return -1;
-    return tn_plan(dtype, M, N, K, has_prologue != 0).n_tickets;
-}
 
 extern "C" int mia_gemm_tn(int dtype, const void* G, int ldg, const void* X, int ldx, float* O, int ldo, int M, int N,
                            int K, const float* pscale, const float* pshift, int pro_act, const float* gate,
-                           int rows_per_img, float* ws, long long ws_floats, int* tickets, int n_tickets,
-                           void* stream) {
+                           int rows_per_img, float* ws, long long ws_floats, void* stream) {
     const int vec = dtype == MIA_BF16 ? 8 : 4;
     MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "mia_gemm_tn: bad dtype %d", dtype);
     MIA_CHECK_ARG(G && X && O, "mia_gemm_tn: null operand");
@@ -1025,43 +989,58 @@ extern "C" int mia_gemm_tn(int dtype, const void* G, int ldg, const void* X, int
     const bool pro = pscale || gate;
     const TnPlan t = tn_plan(dtype, M, N, K, pro);
     p.chunks_per_split = t.chunks_per_split;
-    p.det = 0; p.ws = nullptr; p.tickets = nullptr;
-    p.splits = t.splits; p.group = t.group; p.ngroups = t.ngroups; p.slot = t.slot;
-    if (tickets != nullptr) {
-        // deterministic mode: O is overwritten
+    p.det = 0; p.ws = nullptr; p.splits = t.splits; p.slot = t.slot;
+    if (ws != nullptr || ws_floats < 0) {
+        // deterministic mode (ws_floats < 0 selects it for products that need no workspace): O is overwritten
         MIA_CHECK_ARG(t.ws_floats == 0 || (ws != nullptr && ws_floats >= t.ws_floats),
                       "mia_gemm_tn: workspace of %lld floats needed (mia_gemm_tn_ws_floats), %lld given", t.ws_floats,
                       ws_floats);
-        MIA_CHECK_ARG(n_tickets >= t.n_tickets, "mia_gemm_tn: %d ticket words needed (mia_gemm_tn_tickets), %d given",
-                      t.n_tickets, n_tickets);
         MIA_CHECK_ARG(ldo % 4 == 0 && ((uintptr_t)O % 16) == 0, "mia_gemm_tn: O must be 16-byte aligned with ldo %% 4 == 0");
-        MIA_CHECK_ARG(t.ws_floats * 4 < (1ll << 32), "mia_gemm_tn: workspace beyond 4 GiB");
-        p.det = 1; p.ws = ws; p.ws_bytes = (unsigned)(t.ws_floats * 4); p.tickets = tickets;
+        p.det = 1; p.ws = ws;
     }
     const long long splits = t.splits;
-    dim3 grid(cdiv(N, 128), cdiv(K, 128), (unsigned)splits);
+    const TnShape sh = TN_SHAPES[t.shape];
+    dim3 grid(cdiv(N, sh.tn), cdiv(K, sh.tk), (unsigned)splits);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int layout = K <= 64 ? 1 : (N <= 64 ? 2 : 0);
-#define MIA_TN_LAUNCH(T_, LDS_)                                                                              \
-    do {                                                                                                     \
-        if (pro) {                                                                                           \
-            if (layout == 1) hipLaunchKernelGGL((gemm_tn_kernel<T_, true, 1>), grid, dim3(256), LDS_, s, p);   \
-            else if (layout == 2) hipLaunchKernelGGL((gemm_tn_kernel<T_, true, 2>), grid, dim3(256), LDS_, s, p); \
-            else hipLaunchKernelGGL((gemm_tn_kernel<T_, true, 0>), grid, dim3(256), LDS_, s, p);               \
-        } else {                                                                                             \
-            if (layout == 1) hipLaunchKernelGGL((gemm_tn_kernel<T_, false, 1>), grid, dim3(256), LDS_, s, p);  \
-            else if (layout == 2) hipLaunchKernelGGL((gemm_tn_kernel<T_, false, 2>), grid, dim3(256), LDS_, s, p); \
-            else hipLaunchKernelGGL((gemm_tn_kernel<T_, false, 0>), grid, dim3(256), LDS_, s, p);              \
-        }                                                                                                    \
+#define MIA_TN_GO(T_, TN_, TK_, WR_)                                                                             \
+    do {                                                                                                         \
+        const int esz = (int)sizeof(T_), vec = 16 / esz, br = Mma<T_>::BK;                                       \
+        const int lds = br * ((TN_ + vec) + (TK_ + vec)) * esz + 2 * TK_ * 4;                                    \
+        if (pro) hipLaunchKernelGGL((gemm_tn_kernel<T_, true, TN_, TK_, WR_>), grid, dim3(256), lds, s, p);      \
+        else hipLaunchKernelGGL((gemm_tn_kernel<T_, false, TN_, TK_, WR_>), grid, dim3(256), lds, s, p);         \
     } while (0)
     if (dtype == MIA_BF16) {
-        constexpr int LDS = 2 * 64 * (128 + 8) * 2 + 2 * 128 * 4;
-        MIA_TN_LAUNCH(bf16_t, LDS);
+        switch (t.shape) {
+            case 1: MIA_TN_GO(bf16_t, 128, 64, 4); break;
+            case 2: MIA_TN_GO(bf16_t, 64, 128, 1); break;
+            case 3: MIA_TN_GO(bf16_t, 144, 128, 1); break;
+            case 4: MIA_TN_GO(bf16_t, 128, 144, 4); break;
+            default: MIA_TN_GO(bf16_t, 128, 128, 2); break;
+        }
     } else {
-        constexpr int LDS = 2 * 32 * (128 + 4) * 4 + 2 * 128 * 4;
-        MIA_TN_LAUNCH(float, LDS);
+        switch (t.shape) {
+            case 1: MIA_TN_GO(float, 128, 64, 4); break;
+            case 2: MIA_TN_GO(float, 64, 128, 1); break;
+            default: MIA_TN_GO(float, 128, 128, 2); break;
+        }
     }
-#undef MIA_TN_LAUNCH
+#undef MIA_TN_GO
+    if (p.det && t.splits > 1) {
+        // z-lanes: enough workgroups to fill the chip when the tiles are few and the splits many
+        const int cnt4 = t.slot / 4;
+        int zl = 1;
+        while (zl < 16 && zl * 2 <= t.splits / 4 && (long long)t.tiles * cdiv(cnt4, 256 / zl) < 512) zl *= 2;
+        dim3 fgrid(cdiv(cnt4, 256 / zl), t.tiles);
+        const int tiles_n = cdiv(N, sh.tn);
+#define MIA_TN_FOLD(ZL_) hipLaunchKernelGGL((tn_fold_kernel<ZL_>), fgrid, dim3(256), 0, s, ws, t.splits, t.slot, N, K, \
+                                            sh.tn, sh.tk, tiles_n, O, ldo)
+        if (zl == 1) MIA_TN_FOLD(1);
+        else if (zl == 2) MIA_TN_FOLD(2);
+        else if (zl == 4) MIA_TN_FOLD(4);
+        else if (zl == 8) MIA_TN_FOLD(8);
+        else MIA_TN_FOLD(16);
+#undef MIA_TN_FOLD
+    }
     MIA_CHECK_LAUNCH("mia_gemm_tn");
     return 0;
 }

@@ -123,6 +123,9 @@ class GradReducer:
         # one fused multi-tensor copy packs the bucket, then its all-reduce starts while backward continues
         ready = b["ready"]
         if ready:
+            if ready[0].is_cuda:
+                from .ops import Side
+                Side.sync()     # weight gradients computed on the side stream are complete before they are packed
             views = [b["views"][id(p)] for p in ready]
             torch._foreach_copy_(views, [p.grad for p in ready])
             for p, v in zip(ready, views):

@@ -113,7 +113,6 @@ class GraphedTrainStep:
 
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
-        ops.Tickets.drop()
         ops.Replay.seed_off = self.words.data_ptr()
         optimizer.begin_capture(self.words.data_ptr() + 16, self.MAX_ROWS)
         try:
@@ -122,8 +121,7 @@ class GraphedTrainStep:
         finally:
             ops.Replay.seed_off = None
             self.rows = optimizer.end_capture()
-            ops.Tickets.drop()
-
+    
         # ---- put everything back: neither the warm-up steps nor the capture count as training
         with torch.no_grad():
             for t, s0 in zip(tensors, saved):

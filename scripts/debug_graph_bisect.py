@@ -47,14 +47,12 @@ ref_grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is
 print("eager logits", ref_out[0].tolist())
 g = torch.cuda.CUDAGraph()
 opt.zero_grad(set_to_none=True)
-ops.Tickets.drop()
 if variant == "full":
     opt.begin_capture(words.data_ptr() + 16, 15)
 with torch.cuda.graph(g):
     out, loss = one()
 if variant == "full":
     opt.end_capture()
-ops.Tickets.drop()
 for r in range(3):
     g.replay()
     torch.cuda.synchronize()

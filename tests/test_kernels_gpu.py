@@ -89,15 +89,14 @@ def test_gemm_tn(dtype, M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(400000, 144, 24), (60000, 816, 136), (12800, 1392, 232), (90000, 40, 32)])
 def test_gemm_tn_split_reduction_is_reproducible(M, N, K):
-    """Long reductions are split over many workgroups (two levels of partial sums for the first shape): the partials
-    are added in a fixed order, so repeated launches agree bit for bit, and the counters are left ready for reuse."""
+    """Long reductions are split over many workgroups: the partial tiles are added in a fixed order by a second
+    kernel, so repeated launches agree bit for bit."""
     g, x = rnd(M, N, seed=1, dtype=torch.bfloat16), rnd(M, K, seed=2, dtype=torch.bfloat16)
     outs = [ops.gemm_tn(g, x) for _ in range(4)]
     ref = (g.double().t() @ x.double()).float()
     assert relerr(outs[0], ref) < 2e-3
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
-    assert int(ops.Tickets.get(g.device).abs().sum()) == 0
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
