@@ -68,6 +68,10 @@ int mia_dwconv_fwd(int dtype, const void* x, int B, int H, int W, int C, const f
 int mia_dwconv_bwd_data(int dtype, const void* dy, int B, int H, int W, int C, const float* w, int K, int S, void* dx,
                         const void* yfwd, const float* escale, const float* eshift, const float* emean,
                         const float* erstd, float* stats, int part_rows, void* stream);
+/* Statistics rows mia_dwconv_fwd (kind 0) / mia_dwconv_bwd_data (kind 1) fill for this shape when at most `cap` rows
+ * are allowed (H, W: the forward convolution's INPUT map): passing exactly this count as part_rows avoids the extra
+ * zero-fill launch for rows no workgroup owns. Returns a count (-1: bad shape). */
+int mia_dwconv_part_rows(int dtype, int kind, int B, int H, int W, int C, int K, int S, int cap);
 /* dw[C][k*k] (fp32) = sum dy * pro(x). ws: fp32 scratch of ws_floats >= C*k*k floats (256*C*k*k lets every
  * workgroup row keep its own partial; fewer rows are used when it is smaller). */
 int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int W, int C, const float* pscale,
@@ -117,6 +121,10 @@ int mia_se_gate_fwd(const float* pool_part, int B, int splits, int HW, int C, in
 int mia_se_gate_bwd(const float* dgate_part, int B, int splits, int HW, int C, int RD, const float* Wr,
                     const float* WeT, const float* gate, const float* hpre, const float* pooled, float* dpre2,
                     float* dpre1, float* dpool, float* dWr, float* dbr, float* dWe, float* dbe, void* stream);
+/* The parameter gradients of the two FCs alone, from the dpre2 / dpre1 that mia_se_gate_bwd produced (pass dWr = dbr =
+ * dWe = dbe = NULL there): they are needed by nobody before the optimizer, so a caller can run them on another stream. */
+int mia_se_param_grad(int B, int C, int RD, const float* dpre2, const float* dpre1, const float* pooled,
+                      const float* hpre, float* dWr, float* dbr, float* dWe, float* dbe, void* stream);
 
 /* Backward of a = silu(scale*Y+shift)*gate[b] given dZ = dL/da, in one pass over (Y, dZ): per image and split the
  * five channel sums  dZ*silu(z) | silu'(z)*dZ | silu'(z)*dZ*xhat | silu'(z) | silu'(z)*xhat  (xhat = (Y-mean)*rstd)
@@ -127,6 +135,10 @@ int mia_se_bwd_sums(int dtype, const void* Y, const void* dZ, int B, int HW, int
                     const float* shift, const float* mean, const float* rstd, int splits, float* out, void* stream);
 int mia_se_bn_combine(const float* sums, int B, int splits, int C, const float* gate, const float* dpool, float* part,
                       void* stream);
+/* mia_se_bn_combine + mia_bn_finalize_bwd (P = B) in one launch (same sums in the same order). */
+int mia_se_bn_finalize_bwd(const float* sums, int B, int splits, int C, const float* gate, const float* dpool,
+                           double count, const float* gamma, const float* mean, const float* rstd, int training,
+                           float* dgamma, float* dbeta, float* ca, float* cb, float* cd, void* stream);
 
 /* ---- CBAM (src/model.py:28-108) on an NHWC feature map x [B,H*W,C] -----------------------------------------
  * channel gate (ChannelGate, model.py:45-67): avg/max pool over H*W, shared MLP C->HID->C (ReLU) on both, sum,

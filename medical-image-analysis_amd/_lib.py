@@ -59,7 +59,7 @@ class _Lib:
             fn = getattr(self._dll, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
-            if restype is ctypes.c_int and name not in ("mia_version", "mia_cbam_ws_floats"):
+            if restype is ctypes.c_int and name not in ("mia_version", "mia_cbam_ws_floats", "mia_dwconv_part_rows"):
                 setattr(self, name, self._checked(name, fn))
             else:
                 setattr(self, name, fn)

@@ -1030,6 +1030,35 @@ static int dw_common_checks(const char* name, int dtype, int B, int H, int W, in
     return 0;
 }
 
+// Number of statistics rows a launch fills (= workgroups per channel block) when the caller allows `cap` rows: a caller
+// that passes exactly this many rows as part_rows gets every row written and no zero-fill launch for unowned rows.
+// kind 0: mia_dwconv_fwd, 1: mia_dwconv_bwd_data (H, W are the INPUT map of the forward convolution in both cases).
+extern "C" int mia_dwconv_part_rows(int dtype, int kind, int B, int H, int W, int C, int K, int S, int cap) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (K != 3 && K != 5) || (S != 1 && S != 2) || cap <= 0) return -1;
+    const int pad = (K - 1) / 2;
+    const int OH = (H + 2 * pad - K) / S + 1, OW = (W + 2 * pad - K) / S + 1;
+    const int elem = dtype == MIA_BF16 ? 2 : 4;
+    const int lds = dtype == MIA_BF16 ? 32768 : 65536;
+    DwParams p = {};
+    p.B = B; p.C = C;
+    int gx;
+    int mh, mw, ks = K, ss = S, ph = tile_ph(S);   // map the tiles are counted on, kernel/stride of the tiling
+    if (kind == 0) { mh = OH; mw = OW; }
+    else if (S == 1) { mh = H; mw = W; }
+    else { mh = OH; mw = OW; ks = 3; ss = 1; ph = 1; }   // stride-2 data gradient: tiles of dY cells
+    if (!(kind == 1 && S == 2) && dw_use_mfma(dtype, C, kind == 0 ? S : 1, mh, mw)) {
+        p.OH = mh; p.OW = mw;
+        gx = mfma_grid_for(p, K, kind == 0 ? S : 1);
+    } else {
+        int th, tw;
+        pick_tile(mh, mw, ks, ss, pick_cb(C), elem, ph, DW_NV, 0, lds, &th, &tw);
+        const int total = B * cdiv(mh, th) * cdiv(mw, tw);
+        gx = total < 8192 ? total : 8192;
+        if (gx >= 16) gx &= ~7;
+    }
+    return gx < cap ? gx : cap;
+}
+
 extern "C" int mia_dwconv_fwd(int dtype, const void* x, int B, int H, int W, int C, const float* pscale,
                               const float* pshift, const float* w, int K, int S, void* y, float* stats, int part_rows,
                               void* stream) {

@@ -575,6 +575,65 @@ extern "C" int mia_se_bn_combine(const float* sums, int B, int splits, int C, co
     return 0;
 }
 
+// mia_se_bn_combine followed by mia_bn_finalize_bwd in one launch (one wave per channel, lanes stride over the images in
+// the same order the two-kernel path adds them): the per-image rows
+//   s_b = gate*q0 + dpool*q2,  q_b = gate*q1 + dpool*q3   (q_t = plane t+1 of `sums` summed over the row splits)
+// never reach memory.
+__global__ __launch_bounds__(256) void se_bn_finalize_bwd_kernel(const float* sums, int B, int splits, int C,
+                                                                 const float* gate, const float* dpool, double count,
+                                                                 const float* gamma, const float* mean,
+                                                                 const float* rstd, int training, float* dgamma,
+                                                                 float* dbeta, float* ca, float* cb, float* cd) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= C) return;
+    const size_t plane = (size_t)B * splits * C;
+    double s = 0.0, q = 0.0;
+    for (int b = lane; b < B; b += 64) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < splits; ++k) {
+            const size_t o = ((size_t)b * splits + k) * C + c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] += sums[(e + 1) * plane + o];
+        }
+        const float g = gate[(size_t)b * C + c], dp = dpool[(size_t)b * C + c];
+        s += (double)(g * t[0] + dp * t[2]);
+        q += (double)(g * t[1] + dp * t[3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
+    if (lane == 0) {
+        const double g = gamma ? (double)gamma[c] : 1.0;
+        const double rs = rstd[c], mu = mean[c];
+        if (dgamma) dgamma[c] = (float)q;
+        if (dbeta) dbeta[c] = (float)s;
+        if (training) {
+            ca[c] = (float)(g * rs);
+            cb[c] = (float)(-g * rs * rs * q / count);
+            cd[c] = (float)(g * rs * (-s / count + mu * rs * q / count));
+        } else {
+            ca[c] = (float)(g * rs);
+            cb[c] = 0.f;
+            cd[c] = 0.f;
+        }
+    }
+}
+
+extern "C" int mia_se_bn_finalize_bwd(const float* sums, int B, int splits, int C, const float* gate,
+                                      const float* dpool, double count, const float* gamma, const float* mean,
+                                      const float* rstd, int training, float* dgamma, float* dbeta, float* ca, float* cb,
+                                      float* cd, void* stream) {
+    MIA_CHECK_ARG(sums && gate && dpool && B > 0 && splits > 0 && C > 0 && count > 0 && mean && rstd && ca && cb && cd,
+                  "mia_se_bn_finalize_bwd: bad arguments");
+    hipLaunchKernelGGL(se_bn_finalize_bwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       sums, B, splits, C, gate, dpool, count, gamma, mean, rstd, training, dgamma, dbeta, ca, cb, cd);
+    MIA_CHECK_LAUNCH("mia_se_bn_finalize_bwd");
+    return 0;
+}
+
 // dy = ca * [act'(z) * (G*gate[b] + dpool[b])] + cb*y + cd, written over G   (z = scale*y + shift)
 // W = channels per thread: 4, or 8 (one 16-byte access per lane for bf16) when C % 8 == 0
 template <typename T, int W>
@@ -952,8 +1011,8 @@ extern "C" int mia_se_gate_bwd(const float* dgate_part, int B, int splits, int H
                                const float* WeT, const float* gate, const float* hpre, const float* pooled,
                                float* dpre2, float* dpre1, float* dpool, float* dWr, float* dbr, float* dWe,
                                float* dbe, void* stream) {
-    MIA_CHECK_ARG(dgate_part && Wr && WeT && gate && hpre && pooled && dpre2 && dpre1 && dpool && dWr && dbr && dWe &&
-                      dbe && B > 0 && C > 0 && RD > 0 && HW > 0,
+    MIA_CHECK_ARG(dgate_part && Wr && WeT && gate && hpre && pooled && dpre2 && dpre1 && dpool && B > 0 && C > 0 &&
+                      RD > 0 && HW > 0 && (!dWr == !dbr) && (!dWr == !dWe) && (!dWr == !dbe),
                   "mia_se_gate_bwd: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (se_wide(C, RD)) {
@@ -969,9 +1028,20 @@ extern "C" int mia_se_gate_bwd(const float* dgate_part, int B, int splits, int H
         hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(256), lds, s, dgate_part, splits, 1.0f / (float)HW, C, RD,
                            Wr, WeT, gate, hpre, dpre2, dpre1, dpool);
     }
-    hipLaunchKernelGGL(se_param_grad_kernel, dim3(cdiv((long long)C * RD, 64)), dim3(256), 0, s, B, C, RD, dpre2,
-                       dpre1, pooled, hpre, dWr, dbr, dWe, dbe);
+    if (dWr)
+        hipLaunchKernelGGL(se_param_grad_kernel, dim3(cdiv((long long)C * RD, 64)), dim3(256), 0, s, B, C, RD, dpre2,
+                           dpre1, pooled, hpre, dWr, dbr, dWe, dbe);
     MIA_CHECK_LAUNCH("mia_se_gate_bwd");
+    return 0;
+}
+
+extern "C" int mia_se_param_grad(int B, int C, int RD, const float* dpre2, const float* dpre1, const float* pooled,
+                                 const float* hpre, float* dWr, float* dbr, float* dWe, float* dbe, void* stream) {
+    MIA_CHECK_ARG(dpre2 && dpre1 && pooled && hpre && dWr && dbr && dWe && dbe && B > 0 && C > 0 && RD > 0,
+                  "mia_se_param_grad: bad arguments");
+    hipLaunchKernelGGL(se_param_grad_kernel, dim3(cdiv((long long)C * RD, 64)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), B, C, RD, dpre2, dpre1, pooled, hpre, dWr, dbr, dWe, dbe);
+    MIA_CHECK_LAUNCH("mia_se_param_grad");
     return 0;
 }
 

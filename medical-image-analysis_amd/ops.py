@@ -219,6 +219,8 @@ def dwconv_fwd(x, w, k, s, *, pscale=None, pshift=None, stats_rows=0):
     pad = (k - 1) // 2
     OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
     y = torch.empty((B, OH, OW, C), dtype=x.dtype, device=x.device)
+    if stats_rows:   # exactly the rows the launch fills: no zero-fill launch for the rest
+        stats_rows = lib().mia_dwconv_part_rows(_DT[x.dtype], 0, B, H, W, C, k, s, stats_rows)
     part = torch.empty((stats_rows, 2, C), dtype=torch.float32, device=x.device) if stats_rows else None
     _launch("dwconv_fwd", (x.numel() + y.numel()) * x.element_size(), lib().mia_dwconv_fwd, _DT[x.dtype], _p(x), B, H, W, C, _p(pscale), _p(pshift), _p(w), k, s, _p(y), _p(part),
                          stats_rows, _stream())
@@ -229,6 +231,8 @@ def dwconv_bwd_data(dy, w, k, s, in_hw, *, yfwd=None, escale=None, eshift=None, 
     B, OH, OW, C = dy.shape
     H, W = in_hw
     dx = torch.empty((B, H, W, C), dtype=dy.dtype, device=dy.device)
+    if stats_rows:
+        stats_rows = lib().mia_dwconv_part_rows(_DT[dy.dtype], 1, B, H, W, C, k, s, stats_rows)
     part = torch.empty((stats_rows, 2, C), dtype=torch.float32, device=dy.device) if stats_rows else None
     _launch("dwconv_bwd_data", (dy.numel() + dx.numel() * (2 if yfwd is not None else 1)) * dy.element_size(),
             lib().mia_dwconv_bwd_data, _DT[dy.dtype], _p(dy), B, H, W, C, _p(w), k, s, _p(dx), _p(yfwd), _p(escale),
@@ -355,19 +359,39 @@ def se_gate_fwd(pool_part, hw, wr, br, weT, be):
 
 
 def se_gate_bwd(dgate_part, hw, wr, weT, gate, hpre, pooled):
+    """Backward through the gate: -> (dpool, dpre2, dpre1); the parameter gradients come from se_param_grad."""
     B, splits, C = dgate_part.shape
     RD = wr.shape[0]
     dev = dgate_part.device
     dpre2 = torch.empty((B, C), dtype=torch.float32, device=dev)
     dpre1 = torch.empty((B, RD), dtype=torch.float32, device=dev)
     dpool = torch.empty((B, C), dtype=torch.float32, device=dev)
-    dwr = torch.empty_like(wr)
+    lib().mia_se_gate_bwd(_p(dgate_part), B, splits, hw, C, RD, _p(wr), _p(weT), _p(gate), _p(hpre), _p(pooled),
+                          _p(dpre2), _p(dpre1), _p(dpool), None, None, None, None, _stream())
+    return dpool, dpre2, dpre1
+
+
+def se_param_grad(dpre2, dpre1, pooled, hpre):
+    B, C = dpre2.shape
+    RD = dpre1.shape[1]
+    dev = dpre2.device
+    dwr = torch.empty((RD, C), dtype=torch.float32, device=dev)
     dbr = torch.empty((RD,), dtype=torch.float32, device=dev)
     dwe = torch.empty((C, RD), dtype=torch.float32, device=dev)
     dbe = torch.empty((C,), dtype=torch.float32, device=dev)
-    lib().mia_se_gate_bwd(_p(dgate_part), B, splits, hw, C, RD, _p(wr), _p(weT), _p(gate), _p(hpre), _p(pooled),
-                          _p(dpre2), _p(dpre1), _p(dpool), _p(dwr), _p(dbr), _p(dwe), _p(dbe), _stream())
-    return dpool, dwr, dbr, dwe, dbe
+    lib().mia_se_param_grad(B, C, RD, _p(dpre2), _p(dpre1), _p(pooled), _p(hpre), _p(dwr), _p(dbr), _p(dwe), _p(dbe),
+                            _stream())
+    return dwr, dbr, dwe, dbe
+
+
+def se_bn_finalize_bwd(sums, gate, dpool, count, gamma, stats, training):
+    """se_bn_combine + bn_finalize_bwd in one launch -> coef rows (dgamma, dbeta, ca, cb, cd, unused)."""
+    _, B, splits, C = sums.shape
+    coef = torch.empty((6, C), dtype=torch.float32, device=sums.device)
+    lib().mia_se_bn_finalize_bwd(_p(sums), B, splits, C, _p(gate), _p(dpool), float(count), _p(gamma), _p(stats[2]),
+                                 _p(stats[3]), 1 if training else 0, _p(coef[0]), _p(coef[1]), _p(coef[2]),
+                                 _p(coef[3]), _p(coef[4]), _stream())
+    return coef
 
 
 def stem_im2col(x, dtype):
@@ -577,9 +601,11 @@ class MBConvFn(torch.autograd.Function):
         # ---- squeeze-excite backward ----
         sums = se_bwd_sums(y2, dz, st2)
         wr, weT = _w2d(w_ser), ctx.weT
-        dpool, dwr, dbr, dwe, dbe = se_gate_bwd(sums[0], OH * OW, wr, weT, gate, hpre, pooled)
+        dpool, dpre2, dpre1 = se_gate_bwd(sums[0], OH * OW, wr, weT, gate, hpre, pooled)
+        with side_scope(x.device, wparams + (w_ser, w_see), (dpre2, dpre1, pooled, hpre)):
+            dwr, dbr, dwe, dbe = se_param_grad(dpre2, dpre1, pooled, hpre)
         # ---- bn after depthwise (+SiLU): its reductions come from the same per-image sums ----
-        c2 = bn_finalize_bwd(se_bn_combine(sums, gate, dpool), M2, g2, st2, training)
+        c2 = se_bn_finalize_bwd(sums, gate, dpool, M2, g2, st2, training)
         dy2 = bn_act_bwd_apply(dz, y2, st2, ACT_SILU, c2, gate=gate, dpool=dpool, rows_per_img=OH * OW)
         wdw = w_dw.detach().reshape(Cm, k * k)
         rows_in = part_rows(B * ((H * W + 127) // 128))

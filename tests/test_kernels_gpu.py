@@ -271,6 +271,8 @@ def test_se_bn_one_pass_backward(dtype, C, hw, B):
     assert relerr(sums[0].sum(1), gater.grad) < tol(dtype, 5e-5, 3e-2)
     part = ops.se_bn_combine(sums, gate, dpool)
     coef = ops.bn_finalize_bwd(part, R, gamma, st, True)
+    # the one-launch form of the two kernels above (what the blocks use) agrees to rounding
+    assert relerr(ops.se_bn_finalize_bwd(sums, gate, dpool, R, gamma, st, True)[:5], coef[:5]) < 1e-5
     g = dz.clone()
     dy = ops.bn_act_bwd_apply(g, y, st, ops.ACT_SILU, coef, gate=gate, dpool=dpool, rows_per_img=hw)
     assert dy.data_ptr() == g.data_ptr()
@@ -307,7 +309,8 @@ def test_se_gate_fwd_bwd(C, RD, B, hw):
     assert relerr(gate, g_ref) < 1e-5 and relerr(pooled, p_ref) < 1e-5
     dgate_part = rnd(B, 2, C, seed=6)
     g_ref.backward(dgate_part.sum(1))
-    dpool, dwr, dbr, dwe, dbe = ops.se_gate_bwd(dgate_part, hw, wr, weT, gate, hpre, pooled)
+    dpool, dpre2, dpre1 = ops.se_gate_bwd(dgate_part, hw, wr, weT, gate, hpre, pooled)
+    dwr, dbr, dwe, dbe = ops.se_param_grad(dpre2, dpre1, pooled, hpre)
     # dpool is the per-pixel gradient: d/d(sum over pixels) / hw  == pp.grad of any split
     assert relerr(dpool, pp.grad[:, 0]) < 1e-4
     for mine, ref in ((dwr, wr_.grad), (dbr, br_.grad), (dwe, we_.grad), (dbe, be_.grad)):
