@@ -76,6 +76,10 @@ def main():
     ap.add_argument("--workload", default="b3_cbam", choices=["b3_cbam", "b3_plain"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-linbn", action="store_true",
+                    help="A/B switch: apply BatchNorm backward to the expanded tensor instead of carrying it through "
+                         "the expansion convolution")
+    ap.add_argument("--linbn-min", type=int, default=0, help="A/B: smallest rows x expanded channels for that path")
     ap.add_argument("--no-fork", action="store_true", help="A/B switch: weight gradients on the main stream instead of the side stream")
     ap.add_argument("--kernel-table", action="store_true", help="also print a per-family timing table to stderr")
     args = ap.parse_args()
@@ -104,6 +108,10 @@ def main():
     mia_amd.lib().mia_check_device()
     if args.no_fork:
         ops.Side.enabled = False
+    if args.no_linbn:
+        ops.LinBN.enabled = False
+    if args.linbn_min:
+        ops.LinBN.MIN_ELEMS = args.linbn_min
 
     torch.manual_seed(1234)
     use_attention = args.workload == "b3_cbam"

@@ -109,6 +109,18 @@ int mia_bn_act_bwd_apply(int dtype, void* G, const void* Y, long long R, int C, 
 int mia_affine2(int dtype, const void* X, const void* Y, const void* Res, void* Out, long long R, int C,
                 const float* a, const float* b, const float* d, int act, void* stream);
 
+/* BatchNorm backward carried through a 1x1 convolution (autograd of timm conv_pw + bn1, train.py:370) instead of
+ * being applied to the convolution's wide output: for y = x W^T and dy = ca*g + cb*y + cd,
+ *   dx = g (ca o W) + x S + r      with S = W^T diag(cb) W [Cin][Cin] and r = cd^T W [Cin]        (mia_bn_lin_prep)
+ *   dW = ca o (g^T x) + cb o (W G) + cd (x) cs    with G = x^T x and cs = column sums of x         (mia_bn_lin_fix)
+ * W [Cm][Cin] in the compute dtype (the matrix the forward product used). prep writes WcaT [Cin][Cm] and S in the
+ * compute dtype (B operands of mia_gemm_nt) and r in fp32 (its bias); fix turns dW = g^T x (fp32, from mia_gemm_tn)
+ * into the weight gradient in place, given G and cs in fp32. */
+int mia_bn_lin_prep(int dtype, const void* W, int Cm, int Cin, const float* ca, const float* cb, const float* cd,
+                    void* WcaT, void* S, float* r, void* stream);
+int mia_bn_lin_fix(int dtype, const void* W, int Cm, int Cin, const float* ca, const float* cb, const float* cd,
+                   const float* G, const float* cs, float* dW, void* stream);
+
 /* ---- squeeze-excite: timm SqueezeExcite (mean over H,W -> conv_reduce+bias -> SiLU -> conv_expand+bias -> sigmoid)
  * out[b][split][c] = sum over the split's rows of Wt[r,c] * act(Y*scale+shift)   (Wt optional) */
 int mia_img_colsum(int dtype, const void* Y, const void* Wt, int B, int HW, int C, const float* scale,
@@ -135,10 +147,6 @@ int mia_se_bwd_sums(int dtype, const void* Y, const void* dZ, int B, int HW, int
                     const float* shift, const float* mean, const float* rstd, int splits, float* out, void* stream);
 int mia_se_bn_combine(const float* sums, int B, int splits, int C, const float* gate, const float* dpool, float* part,
                       void* stream);
-/* mia_se_bn_combine + mia_bn_finalize_bwd (P = B) in one launch (same sums in the same order). */
-int mia_se_bn_finalize_bwd(const float* sums, int B, int splits, int C, const float* gate, const float* dpool,
-                           double count, const float* gamma, const float* mean, const float* rstd, int training,
-                           float* dgamma, float* dbeta, float* ca, float* cb, float* cd, void* stream);
 
 /* ---- CBAM (src/model.py:28-108) on an NHWC feature map x [B,H*W,C] -----------------------------------------
  * channel gate (ChannelGate, model.py:45-67): avg/max pool over H*W, shared MLP C->HID->C (ReLU) on both, sum,

@@ -195,17 +195,35 @@ __device__ __forceinline__ f4 to_f4(const f22& v) { return {v.lo.x, v.lo.y, v.hi
 __device__ __forceinline__ f22 to_f22(const f4& v) { return {v2f{v.x, v.y}, v2f{v.z, v.w}}; }
 
 // ----------------------------------------------------------------------------------------------
-// wave (64-lane) reductions via DPP-lowered shuffles
+// wave (64-lane) reductions. Inside a row of 16 lanes the partners come through DPP operand modifiers (quad
+// permutes, then the half-row and full-row mirrors): four VALU instructions, no LDS crossbar trip as a lane shuffle
+// (ds_bpermute) would take. The four row results are then read as scalars and combined, which also broadcasts the
+// total to every lane.
 // ----------------------------------------------------------------------------------------------
+#define MIA_DPP_QUAD_XOR1 0xB1      // quad_perm [1,0,3,2]
+#define MIA_DPP_QUAD_XOR2 0x4E      // quad_perm [2,3,0,1]
+#define MIA_DPP_ROW_HALF_MIRROR 0x141
+#define MIA_DPP_ROW_MIRROR 0x140
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_f32(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f32<MIA_DPP_QUAD_XOR1>(v);
+    v += dpp_f32<MIA_DPP_QUAD_XOR2>(v);
+    v += dpp_f32<MIA_DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_f32<MIA_DPP_ROW_MIRROR>(v);
+    return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f32<MIA_DPP_QUAD_XOR1>(v));
+    v = fmaxf(v, dpp_f32<MIA_DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, dpp_f32<MIA_DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f32<MIA_DPP_ROW_MIRROR>(v));
+    return fmaxf(fmaxf(lane_f32(v, 0), lane_f32(v, 16)), fmaxf(lane_f32(v, 32), lane_f32(v, 48)));
 }
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

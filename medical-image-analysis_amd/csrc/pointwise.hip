@@ -575,65 +575,6 @@ extern "C" int mia_se_bn_combine(const float* sums, int B, int splits, int C, co
     return 0;
 }
 
-// mia_se_bn_combine followed by mia_bn_finalize_bwd in one launch (one wave per channel, lanes stride over the images in
-// the same order the two-kernel path adds them): the per-image rows
-//   s_b = gate*q0 + dpool*q2,  q_b = gate*q1 + dpool*q3   (q_t = plane t+1 of `sums` summed over the row splits)
-// never reach memory.
-__global__ __launch_bounds__(256) void se_bn_finalize_bwd_kernel(const float* sums, int B, int splits, int C,
-                                                                 const float* gate, const float* dpool, double count,
-                                                                 const float* gamma, const float* mean,
-                                                                 const float* rstd, int training, float* dgamma,
-                                                                 float* dbeta, float* ca, float* cb, float* cd) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 4 + wave;
-    if (c >= C) return;
-    const size_t plane = (size_t)B * splits * C;
-    double s = 0.0, q = 0.0;
-    for (int b = lane; b < B; b += 64) {
-        float t[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < splits; ++k) {
-            const size_t o = ((size_t)b * splits + k) * C + c;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) t[e] += sums[(e + 1) * plane + o];
-        }
-        const float g = gate[(size_t)b * C + c], dp = dpool[(size_t)b * C + c];
-        s += (double)(g * t[0] + dp * t[2]);
-        q += (double)(g * t[1] + dp * t[3]);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s += __shfl_xor(s, o, 64);
-        q += __shfl_xor(q, o, 64);
-    }
-    if (lane == 0) {
-        const double g = gamma ? (double)gamma[c] : 1.0;
-        const double rs = rstd[c], mu = mean[c];
-        if (dgamma) dgamma[c] = (float)q;
-        if (dbeta) dbeta[c] = (float)s;
-        if (training) {
-            ca[c] = (float)(g * rs);
-            cb[c] = (float)(-g * rs * rs * q / count);
-            cd[c] = (float)(g * rs * (-s / count + mu * rs * q / count));
-        } else {
-            ca[c] = (float)(g * rs);
-            cb[c] = 0.f;
-            cd[c] = 0.f;
-        }
-    }
-}
-
-extern "C" int mia_se_bn_finalize_bwd(const float* sums, int B, int splits, int C, const float* gate,
-                                      const float* dpool, double count, const float* gamma, const float* mean,
-                                      const float* rstd, int training, float* dgamma, float* dbeta, float* ca, float* cb,
-                                      float* cd, void* stream) {
-    MIA_CHECK_ARG(sums && gate && dpool && B > 0 && splits > 0 && C > 0 && count > 0 && mean && rstd && ca && cb && cd,
-                  "mia_se_bn_finalize_bwd: bad arguments");
-    hipLaunchKernelGGL(se_bn_finalize_bwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       sums, B, splits, C, gate, dpool, count, gamma, mean, rstd, training, dgamma, dbeta, ca, cb, cd);
-    MIA_CHECK_LAUNCH("mia_se_bn_finalize_bwd");
-    return 0;
-}
-
 // dy = ca * [act'(z) * (G*gate[b] + dpool[b])] + cb*y + cd, written over G   (z = scale*y + shift)
 // W = channels per thread: 4, or 8 (one 16-byte access per lane for bf16) when C % 8 == 0
 template <typename T, int W>
@@ -1042,6 +983,102 @@ extern "C" int mia_se_param_grad(int B, int C, int RD, const float* dpre2, const
     hipLaunchKernelGGL(se_param_grad_kernel, dim3(cdiv((long long)C * RD, 64)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), B, C, RD, dpre2, dpre1, pooled, hpre, dWr, dbr, dWe, dbe);
     MIA_CHECK_LAUNCH("mia_se_param_grad");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm backward carried THROUGH a 1x1 convolution instead of being applied to its (wide) output.
+// For y = x W^T (x [M,Cin] narrow, y [M,Cm] wide) followed by train-mode BatchNorm, the gradient with respect to y is
+// dy = ca*g + cb*y + cd per channel (g = gradient w.r.t. the normalised tensor). Both consumers of dy are linear, so
+//   dx = dy W        = g (ca o W) + x S + r,        S = W^T diag(cb) W  [Cin,Cin],  r = cd^T W  [Cin]
+//   dW = dy^T x      = ca o (g^T x) + cb o (W G) + cd (x) cs,   G = x^T x  [Cin,Cin],  cs = column sums of x
+// and dy itself (three passes over the widest tensor of the block) is never formed. Worth it where M*Cm is large and
+// Cin small (the first stages: Cin <= 64); the weight-sized products below are then a few thousand outputs.
+// ------------------------------------------------------------------------------------------------
+// blocks [0, nS): 16x16 tiles of S (and r from the tiles of the first tile row); blocks [nS, ...): (ca o W)^T
+template <typename T>
+__global__ __launch_bounds__(256) void bn_lin_prep_kernel(const T* __restrict__ W, int Cm, int Cin,
+                                                          const float* __restrict__ ca, const float* __restrict__ cb,
+                                                          const float* __restrict__ cd, T* __restrict__ WcaT,
+                                                          T* __restrict__ S, float* __restrict__ r, int nS) {
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= nS) {
+        const int idx = ((int)blockIdx.x - nS) * 256 + tid;   // element (j, c) of WcaT [Cin][Cm]
+        if (idx < Cin * Cm) {
+            const int j = idx / Cm, c = idx - j * Cm;
+            WcaT[idx] = from_f32<T>(to_f32<T>(W[(size_t)c * Cin + j]) * ca[c]);
+        }
+        return;
+    }
+    __shared__ float wi[64][17], wj[64][17], cds[64];
+    const int tiles = (Cin + 15) / 16;
+    const int i0 = ((int)blockIdx.x / tiles) * 16, j0 = ((int)blockIdx.x % tiles) * 16;
+    const int ti = tid >> 4, tj = tid & 15;
+    float acc = 0.f, racc = 0.f;
+    for (int c0 = 0; c0 < Cm; c0 += 64) {
+        __syncthreads();
+        for (int e = tid; e < 64 * 16; e += 256) {
+            const int cc = e >> 4, k = e & 15, c = c0 + cc;
+            const bool ok = c < Cm;
+            const float wiv = (ok && i0 + k < Cin) ? to_f32<T>(W[(size_t)c * Cin + i0 + k]) : 0.f;
+            const float wjv = (ok && j0 + k < Cin) ? to_f32<T>(W[(size_t)c * Cin + j0 + k]) : 0.f;
+            wi[cc][k] = ok ? wiv * cb[c] : 0.f;
+            wj[cc][k] = wjv;
+        }
+        if (tid < 64) cds[tid] = (c0 + tid < Cm) ? cd[c0 + tid] : 0.f;
+        __syncthreads();
+#pragma unroll 8
+        for (int cc = 0; cc < 64; ++cc) {
+            acc += wi[cc][ti] * wj[cc][tj];
+            if (ti == 0) racc += cds[cc] * wj[cc][tj];
+        }
+    }
+    if (i0 + ti < Cin && j0 + tj < Cin) S[(size_t)(i0 + ti) * Cin + j0 + tj] = from_f32<T>(acc);
+    if (i0 == 0 && ti == 0 && j0 + tj < Cin) r[j0 + tj] = racc;
+}
+
+// dW[c][j] = ca[c]*T1[c][j] + cb[c]*sum_i W[c][i]*G[i][j] + cd[c]*cs[j], written over T1 (= g^T x)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_lin_fix_kernel(const T* __restrict__ W, int Cm, int Cin,
+                                                         const float* __restrict__ ca, const float* __restrict__ cb,
+                                                         const float* __restrict__ cd, const float* __restrict__ G,
+                                                         const float* __restrict__ cs, float* __restrict__ dW) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Cm * Cin) return;
+    const int c = idx / Cin, j = idx - c * Cin;
+    float wg = 0.f;
+    for (int i = 0; i < Cin; ++i) wg += to_f32<T>(W[(size_t)c * Cin + i]) * G[(size_t)i * Cin + j];
+    dW[idx] = ca[c] * dW[idx] + cb[c] * wg + cd[c] * cs[j];
+}
+
+extern "C" int mia_bn_lin_prep(int dtype, const void* W, int Cm, int Cin, const float* ca, const float* cb,
+                               const float* cd, void* WcaT, void* S, float* r, void* stream) {
+    MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "mia_bn_lin_prep: bad dtype %d", dtype);
+    MIA_CHECK_ARG(W && ca && cb && cd && WcaT && S && r && Cm > 0 && Cin > 0, "mia_bn_lin_prep: bad arguments");
+    const int tiles = cdiv(Cin, 16), nS = tiles * tiles;
+    dim3 grid((unsigned)(nS + cdiv((long long)Cm * Cin, 256)));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIA_BF16)
+        hipLaunchKernelGGL(bn_lin_prep_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)W, Cm, Cin, ca, cb, cd,
+                           (bf16_t*)WcaT, (bf16_t*)S, r, nS);
+    else
+        hipLaunchKernelGGL(bn_lin_prep_kernel<float>, grid, dim3(256), 0, s, (const float*)W, Cm, Cin, ca, cb, cd,
+                           (float*)WcaT, (float*)S, r, nS);
+    MIA_CHECK_LAUNCH("mia_bn_lin_prep");
+    return 0;
+}
+
+extern "C" int mia_bn_lin_fix(int dtype, const void* W, int Cm, int Cin, const float* ca, const float* cb,
+                              const float* cd, const float* G, const float* cs, float* dW, void* stream) {
+    MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "mia_bn_lin_fix: bad dtype %d", dtype);
+    MIA_CHECK_ARG(W && ca && cb && cd && G && cs && dW && Cm > 0 && Cin > 0, "mia_bn_lin_fix: bad arguments");
+    dim3 grid((unsigned)cdiv((long long)Cm * Cin, 256));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIA_BF16)
+        hipLaunchKernelGGL(bn_lin_fix_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)W, Cm, Cin, ca, cb, cd, G, cs, dW);
+    else
+        hipLaunchKernelGGL(bn_lin_fix_kernel<float>, grid, dim3(256), 0, s, (const float*)W, Cm, Cin, ca, cb, cd, G, cs, dW);
+    MIA_CHECK_LAUNCH("mia_bn_lin_fix");
     return 0;
 }
 

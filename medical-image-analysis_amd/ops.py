@@ -384,14 +384,39 @@ def se_param_grad(dpre2, dpre1, pooled, hpre):
     return dwr, dbr, dwe, dbe
 
 
-def se_bn_finalize_bwd(sums, gate, dpool, count, gamma, stats, training):
-    """se_bn_combine + bn_finalize_bwd in one launch -> coef rows (dgamma, dbeta, ca, cb, cd, unused)."""
-    _, B, splits, C = sums.shape
-    coef = torch.empty((6, C), dtype=torch.float32, device=sums.device)
-    lib().mia_se_bn_finalize_bwd(_p(sums), B, splits, C, _p(gate), _p(dpool), float(count), _p(gamma), _p(stats[2]),
-                                 _p(stats[3]), 1 if training else 0, _p(coef[0]), _p(coef[1]), _p(coef[2]),
-                                 _p(coef[3]), _p(coef[4]), _stream())
-    return coef
+def bn_lin_prep(w, coef):
+    """w [Cm,Cin] (compute dtype), coef rows (.., .., ca, cb, cd, ..) -> (WcaT [Cin,Cm], S [Cin,Cin], r [Cin] fp32)."""
+    Cm, Cin = w.shape
+    wcaT = torch.empty((Cin, Cm), dtype=w.dtype, device=w.device)
+    S = torch.empty((Cin, Cin), dtype=w.dtype, device=w.device)
+    r = torch.empty((Cin,), dtype=torch.float32, device=w.device)
+    lib().mia_bn_lin_prep(_DT[w.dtype], _p(w), Cm, Cin, _p(coef[2]), _p(coef[3]), _p(coef[4]), _p(wcaT), _p(S), _p(r),
+                          _stream())
+    return wcaT, S, r
+
+
+def bn_lin_fix(t1, w, coef, G, cs):
+    """In place on t1 = g^T x [Cm,Cin] fp32 -> the weight gradient of the convolution in front of the BatchNorm."""
+    Cm, Cin = w.shape
+    lib().mia_bn_lin_fix(_DT[w.dtype], _p(w), Cm, Cin, _p(coef[2]), _p(coef[3]), _p(coef[4]), _p(G), _p(cs), _p(t1),
+                         _stream())
+    return t1
+
+
+class LinBN:
+    """BatchNorm backward carried through the expansion convolution (mia_bn_lin_prep / mia_bn_lin_fix) where the
+    expanded tensor is large and the block input narrow: there the three passes over the expanded tensor that
+    applying dy = ca*g + cb*y + cd costs are the most expensive thing in the block's backward."""
+    enabled = True
+    # rows x expanded channels. Measured on the B3 step at batch 128 (ms per step): off 24.9; from 300 M (block 1.0
+    # only) 24.56; from 100 M (blocks 1.0-2.0) 24.23; from 40 M (also the 38x38 blocks) 25.1 - below ~100 M elements the
+    # extra small launches cost more than the three passes they save
+    MIN_ELEMS = 100_000_000
+    MAX_CIN = 64
+
+    @classmethod
+    def use(cls, M, Cm, Cin):
+        return cls.enabled and Cin <= cls.MAX_CIN and M * Cm >= cls.MIN_ELEMS
 
 
 def stem_im2col(x, dtype):
@@ -571,6 +596,7 @@ class MBConvFn(torch.autograd.Function):
         ctx.cfg, ctx.training = cfg, training
         # casts made once per step: the transposed copies serve the data-gradient GEMMs of the backward
         ctx.wexpT, ctx.wprojT, ctx.weT = wexpT, wprojT, weT
+        ctx.wexp = wexp if (cfg.kind == "ir" and need_bwd) else None
         ctx.save_for_backward(x, y1, st1, y2, st2, y3, st3, pooled, hpre, gate, w_exp, g1, w_dw, g2, w_ser, w_see,
                               w_proj, g3)
         return out
@@ -605,7 +631,7 @@ class MBConvFn(torch.autograd.Function):
         with side_scope(x.device, wparams + (w_ser, w_see), (dpre2, dpre1, pooled, hpre)):
             dwr, dbr, dwe, dbe = se_param_grad(dpre2, dpre1, pooled, hpre)
         # ---- bn after depthwise (+SiLU): its reductions come from the same per-image sums ----
-        c2 = se_bn_finalize_bwd(sums, gate, dpool, M2, g2, st2, training)
+        c2 = bn_finalize_bwd(se_bn_combine(sums, gate, dpool), M2, g2, st2, training)
         dy2 = bn_act_bwd_apply(dz, y2, st2, ACT_SILU, c2, gate=gate, dpool=dpool, rows_per_img=OH * OW)
         wdw = w_dw.detach().reshape(Cm, k * k)
         rows_in = part_rows(B * ((H * W + 127) // 128))
@@ -616,10 +642,23 @@ class MBConvFn(torch.autograd.Function):
             g1t, part = dwconv_bwd_data(dy2, wdw, k, s, (H, W), yfwd=y1, escale=st1[0], eshift=st1[1], emean=st1[2],
                                         erstd=st1[3], stats_rows=rows_in)
             c1 = bn_finalize_bwd(part, M, g1, st1, training)
-            dy1 = affine2(g1t, c1[2], c1[4], y=y1, b=c1[3], out=g1t).view(M, Cm)
-            with side_scope(x.device, wparams, (dy1, x)):
-                dwexp = gemm_tn(dy1, x.view(M, Cin))
-            dx, _ = gemm_nt(dy1, ctx.wexpT, add=dout.view(M, Cin) if cfg.has_skip else None)
+            x2d = x.view(M, Cin)
+            if LinBN.use(M, Cm, Cin):
+                # dy1 = ca*g + cb*y1 + cd is never formed: both products that consume it are linear in it
+                g2d = g1t.view(M, Cm)
+                wcaT, S, r = bn_lin_prep(ctx.wexp, c1)
+                with side_scope(x.device, wparams, (g1t, x, c1, ctx.wexp)):
+                    t1 = gemm_tn(g2d, x2d)
+                    G = gemm_tn(x2d, x2d)
+                    cs = img_colsum(x, None, None, None, ACT_NONE).sum((0, 1))
+                    dwexp = bn_lin_fix(t1, ctx.wexp, c1, G, cs)
+                xs, _ = gemm_nt(x2d, S, bias=r, add=dout.view(M, Cin) if cfg.has_skip else None)
+                dx, _ = gemm_nt(g2d, wcaT, add=xs)
+            else:
+                dy1 = affine2(g1t, c1[2], c1[4], y=y1, b=c1[3], out=g1t).view(M, Cm)
+                with side_scope(x.device, wparams, (dy1, x)):
+                    dwexp = gemm_tn(dy1, x2d)
+                dx, _ = gemm_nt(dy1, ctx.wexpT, add=dout.view(M, Cin) if cfg.has_skip else None)
             dx = dx.view(B, H, W, Cin)
             return (dx, dwexp.view_as(w_exp), c1[0], c1[1], ddw, c2[0], c2[1], dwr.view_as(w_ser), dbr,
                     dwe.view_as(w_see), dbe, dwproj.view_as(w_proj), c3[0], c3[1], None)

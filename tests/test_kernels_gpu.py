@@ -271,8 +271,6 @@ def test_se_bn_one_pass_backward(dtype, C, hw, B):
     assert relerr(sums[0].sum(1), gater.grad) < tol(dtype, 5e-5, 3e-2)
     part = ops.se_bn_combine(sums, gate, dpool)
     coef = ops.bn_finalize_bwd(part, R, gamma, st, True)
-    # the one-launch form of the two kernels above (what the blocks use) agrees to rounding
-    assert relerr(ops.se_bn_finalize_bwd(sums, gate, dpool, R, gamma, st, True)[:5], coef[:5]) < 1e-5
     g = dz.clone()
     dy = ops.bn_act_bwd_apply(g, y, st, ops.ACT_SILU, coef, gate=gate, dpool=dpool, rows_per_img=hw)
     assert dy.data_ptr() == g.data_ptr()

@@ -63,6 +63,44 @@ def test_block_matches_oracle_fp32(kind, cin, cout, k, s, e, H, W, train):
             assert int(b) == int(br[n]), n
 
 
+@pytest.mark.parametrize("kind,cin,cout,k,s,e,H,W", [b for b in BLOCKS if b[0] == "ir" and b[1] <= 64])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_block_backward_with_batchnorm_carried_through_the_expansion(kind, cin, cout, k, s, e, H, W, dtype, monkeypatch):
+    """The backward variant used for large maps (BatchNorm backward carried through the expansion convolution,
+    dy1 never formed), forced on at a small shape: fp32 against the CPU oracle at the block tolerances, bf16 against
+    the same block run the ordinary way (same storage rounding, so the two agree far inside bf16 noise)."""
+    from mia_amd import ops
+    ref = O.IRBlock(cin, cout, k, s, e)
+    sd = seeded_state_dict(ref, 5)
+    ref.load_state_dict(sd)
+    x = randn(6, 3, cin, H, W)
+    g = None
+    results = {}
+    for forced in (True, False):
+        monkeypatch.setattr(ops.LinBN, "MIN_ELEMS", 0 if forced else 1 << 60)
+        mine = MBConv(kind, cin, cout, k, s, e)
+        mine.load_state_dict(sd)
+        mine.cuda().train()
+        xm = nhwc(x).cuda().to(dtype).requires_grad_(True)
+        ym = mine(xm)
+        if g is None:
+            g = randn(7, *ym.permute(0, 3, 1, 2).shape)
+        ym.backward(nhwc(g).cuda().to(dtype))
+        results[forced] = (xm.grad.float(), {n: p.grad.clone() for n, p in mine.named_parameters()})
+    if dtype == torch.float32:
+        ref.train()
+        xr = x.clone().requires_grad_(True)
+        ref(xr).backward(g)
+        assert relerr(results[True][0].permute(0, 3, 1, 2), xr.grad) < 2e-4
+        pr = dict(ref.named_parameters())
+        for n, gr in results[True][1].items():
+            assert relerr(gr, pr[n].grad) < 3e-4, n
+    else:
+        assert relerr(results[True][0], results[False][0]) < 2e-2
+        for n, gr in results[True][1].items():
+            assert relerr(gr, results[False][1][n]) < 2e-2, n
+
+
 def test_trunk_features_match_oracle_fp32_64px():
     ref = O.EfficientNetB3Features()
     sd = seeded_state_dict(ref, 9)
