@@ -178,7 +178,7 @@ int mia_cbam_bwd(int dtype, const void* dx2, const void* x, int B, int H, int W,
 /* ---- multi-head self-attention core (MultiHeadAttentionClassifier.forward, model.py:153-163) --------------------
  * qkv [B*HW, 3C] (query | key | value projections, head h = columns h*HD..) -> out [B*HW, C];
  * softmax(QK^T/sqrt(HD)) is written to P [B,heads,HW,HW] (fp32) for the backward; dropout(pdrop) on the weights
- * uses a counter-based mask from `seed` that the backward regenerates. HW <= 256, HD in {8,16,32,48,64}.
+ * uses a counter-based mask from `seed` that the backward regenerates. HW <= 256, HD in {8,16,24,32,48,64,96,128}.
  * seed_offset (nullable, here and in every entry point that takes a seed): a counter in DEVICE memory added to the
  * seed (times an odd constant) at launch time, so that a captured HIP graph, which replays fixed arguments, draws
  * new masks on every replay when the caller rewrites the counter before it (mia_set_words). */
@@ -284,7 +284,7 @@ int mia_upsample_concat_fwd(int dtype, const void* x, int B, int h, int w, int C
 int mia_upsample_concat_bwd(int dtype, const void* dout, int B, int h, int w, int C1, int C2, int H, int W, void* dx,
                             void* dskip, void* stream);
 /* final_conv = nn.Conv2d(16, num_classes, 1) (model.py:214, :237): logits [B][n][HW] fp32 (NCHW) from x [B,HW,C];
- * Wt [n][C], bias [n] (nullable). C % 4 == 0, C <= 64, n <= 8. */
+ * Wt [n][C], bias [n] (nullable). C % 4 == 0, C <= 64, n <= 32. */
 int mia_pixel_linear_fwd(int dtype, const void* x, int B, int HW, int C, int n, const float* Wt, const float* bias,
                          float* logits, void* stream);
 /* dx [B,HW,C]; partial [partial_rows][n*C + n] = per-workgroup sums of (dWt, dbias): column-sum them. */
@@ -295,7 +295,7 @@ int mia_channel_dropout_mask(float* mask, int B, int C, float p, unsigned long l
                              const unsigned long long* seed_offset, void* stream);
 /* loss = ce_weight * CrossEntropy(logits, target, weight=class_weights) + overlap_weight * (1 - mean score),
  * score = Dice (iou = 0) or IoU (iou = 1) per (image, class) on softmax probabilities. logits [B][n][HW] fp32,
- * target [B][HW] int64, n <= 8. partial: [B*splits][3n+2] scratch; coef: [1 + 2*B*n] kept for the backward. */
+ * target [B][HW] int64, n <= 32. partial: [B*splits][3n+2] scratch; coef: [1 + 2*B*n] kept for the backward. */
 int mia_seg_loss_fwd(const float* logits, const long long* target, int B, int HW, int n, const float* class_weights,
                      int iou, float smooth, float ce_weight, float overlap_weight, int splits, float* partial,
                      float* coef, float* loss, void* stream);

@@ -1052,8 +1052,11 @@ static int launch_attention(bool fwd, const void* qkv, const float* P, const voi
     if (HD == 48) MIA_ATT(48);
     else if (HD == 8) MIA_ATT(8);
     else if (HD == 16) MIA_ATT(16);
+    else if (HD == 24) MIA_ATT(24);
     else if (HD == 32) MIA_ATT(32);
     else if (HD == 64) MIA_ATT(64);
+    else if (HD == 96) MIA_ATT(96);
+    else if (HD == 128) MIA_ATT(128);
     else return -1;
 #undef MIA_ATT
     return 0;
@@ -1063,7 +1066,8 @@ static int attention_checks(const char* name, int B, int HW, int C, int heads) {
     MIA_CHECK_ARG(B > 0 && HW > 0 && HW <= 256 && C > 0 && heads > 0 && C % heads == 0,
                   "%s: bad shape B=%d tokens=%d C=%d heads=%d (tokens <= 256)", name, B, HW, C, heads);
     const int hd = C / heads;
-    MIA_CHECK_ARG(hd == 8 || hd == 16 || hd == 32 || hd == 48 || hd == 64, "%s: head_dim %d not built (8,16,32,48,64)", name, hd);
+    MIA_CHECK_ARG(hd == 8 || hd == 16 || hd == 24 || hd == 32 || hd == 48 || hd == 64 || hd == 96 || hd == 128,
+                  "%s: head_dim %d not built (8,16,24,32,48,64,96,128)", name, hd);
     return 0;
 }
 

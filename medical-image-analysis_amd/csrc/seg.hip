@@ -3,6 +3,7 @@
 // logits, channel-dropout masks, and the cross-entropy + Dice / IoU segmentation loss.
 // Activations are NHWC [B, H, W, C] in the compute dtype T; all arithmetic is fp32.
 #include "common.h"
+#include <type_traits>
 
 static inline unsigned grid_for(long long items, int cap = 16384) {
     long long b = (items + 255) / 256;
@@ -226,25 +227,26 @@ extern "C" int mia_upsample_concat_bwd(int dtype, const void* dout, int B, int h
 // ------------------------------------------------------------------------------------------------
 // final 1x1 convolution: logits[b][k][p] (NCHW, fp32) = bias[k] + sum_c x[b,p,c] * Wt[k][c]
 // ------------------------------------------------------------------------------------------------
-#define SEG_MAXN 8
+// classes per pixel are held in registers: kernels are built for up to 8 (the reference's heads have 1-4) and up to 32
+#define SEG_MAXN 32
 #define SEG_MAXC 64
 
-template <typename T>
+template <typename T, int MAXN>
 __global__ __launch_bounds__(256) void pixel_linear_fwd_kernel(const T* x, int B, int HW, int C, int n, const float* Wt,
                                                                const float* bias, float* logits) {
-    __shared__ float ws[SEG_MAXN * SEG_MAXC + SEG_MAXN];
+    __shared__ float ws[MAXN * SEG_MAXC + MAXN];
     for (int i = threadIdx.x; i < n * C; i += 256) ws[i] = Wt[i];
-    if (threadIdx.x < n) ws[SEG_MAXN * SEG_MAXC + threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+    if (threadIdx.x < n) ws[MAXN * SEG_MAXC + threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
     __syncthreads();
     const long long total = (long long)B * HW;
     for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (long long)gridDim.x * 256) {
-        float acc[SEG_MAXN];
+        float acc[MAXN];
 #pragma unroll
-        for (int k = 0; k < SEG_MAXN; ++k) acc[k] = ws[SEG_MAXN * SEG_MAXC + (k < n ? k : 0)];
+        for (int k = 0; k < MAXN; ++k) acc[k] = ws[MAXN * SEG_MAXC + (k < n ? k : 0)];
         for (int c = 0; c < C; c += 4) {
             const f4 v = load4<T>(x + (size_t)pix * C + c);
 #pragma unroll
-            for (int k = 0; k < SEG_MAXN; ++k)
+            for (int k = 0; k < MAXN; ++k)
                 if (k < n) {
                     const float* wk = ws + k * C + c;
                     acc[k] += v.x * wk[0] + v.y * wk[1] + v.z * wk[2] + v.w * wk[3];
@@ -252,28 +254,28 @@ __global__ __launch_bounds__(256) void pixel_linear_fwd_kernel(const T* x, int B
         }
         const long long b = pix / HW, p = pix % HW;
 #pragma unroll
-        for (int k = 0; k < SEG_MAXN; ++k)
+        for (int k = 0; k < MAXN; ++k)
             if (k < n) logits[((size_t)b * n + k) * HW + p] = acc[k];
     }
 }
 
 // dx[b,p,c] = sum_k dl[b][k][p] * Wt[k][c]
-template <typename T>
+template <typename T, int MAXN>
 __global__ __launch_bounds__(256) void pixel_linear_bwd_data_kernel(const float* dl, int B, int HW, int C, int n,
                                                                     const float* Wt, T* dx) {
-    __shared__ float ws[SEG_MAXN * SEG_MAXC];
+    __shared__ float ws[MAXN * SEG_MAXC];
     for (int i = threadIdx.x; i < n * C; i += 256) ws[i] = Wt[i];
     __syncthreads();
     const long long total = (long long)B * HW;
     for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (long long)gridDim.x * 256) {
         const long long b = pix / HW, p = pix % HW;
-        float g[SEG_MAXN];
+        float g[MAXN];
 #pragma unroll
-        for (int k = 0; k < SEG_MAXN; ++k) g[k] = k < n ? dl[((size_t)b * n + k) * HW + p] : 0.f;
+        for (int k = 0; k < MAXN; ++k) g[k] = k < n ? dl[((size_t)b * n + k) * HW + p] : 0.f;
         for (int c = 0; c < C; c += 4) {
             f4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < SEG_MAXN; ++k)
+            for (int k = 0; k < MAXN; ++k)
                 if (k < n) {
                     const float* wk = ws + k * C + c;
                     o = {o.x + g[k] * wk[0], o.y + g[k] * wk[1], o.z + g[k] * wk[2], o.w + g[k] * wk[3]};
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256) void pixel_linear_bwd_data_kernel(const float*
 
 // partial[blk][k][c] = sum over the block's pixels of dl[k] * x[c];  partial[blk][n*C + k] = sum dl[k]
 // 256 threads = (256 / (C/4)) pixel lanes x (C/4) channel-vector lanes
-template <typename T>
+template <typename T, int MAXN>
 __global__ __launch_bounds__(256) void pixel_linear_bwd_weight_kernel(const T* x, const float* dl, int B, int HW, int C,
                                                                       int n, float* partial) {
     __shared__ f4 red[256];
@@ -293,17 +295,17 @@ __global__ __launch_bounds__(256) void pixel_linear_bwd_weight_kernel(const T* x
     const int cvn = C >> 2, pl = 256 / cvn;
     const int cvl = threadIdx.x % cvn, plane = threadIdx.x / cvn;
     const bool active = plane < pl;
-    f4 acc[SEG_MAXN];
-    float bs[SEG_MAXN];
+    f4 acc[MAXN];
+    float bs[MAXN];
 #pragma unroll
-    for (int k = 0; k < SEG_MAXN; ++k) { acc[k] = {0.f, 0.f, 0.f, 0.f}; bs[k] = 0.f; }
+    for (int k = 0; k < MAXN; ++k) { acc[k] = {0.f, 0.f, 0.f, 0.f}; bs[k] = 0.f; }
     const long long total = (long long)B * HW;
     if (active)
         for (long long pix = (long long)blockIdx.x * pl + plane; pix < total; pix += (long long)gridDim.x * pl) {
             const long long b = pix / HW, p = pix % HW;
             const f4 v = load4<T>(x + (size_t)pix * C + cvl * 4);
 #pragma unroll
-            for (int k = 0; k < SEG_MAXN; ++k)
+            for (int k = 0; k < MAXN; ++k)
                 if (k < n) {
                     const float g = dl[((size_t)b * n + k) * HW + p];
                     acc[k] = {acc[k].x + g * v.x, acc[k].y + g * v.y, acc[k].z + g * v.z, acc[k].w + g * v.w};
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(256) void pixel_linear_bwd_weight_kernel(const T* x
         }
     float* out = partial + (size_t)blockIdx.x * (n * C + n);
 #pragma unroll
-    for (int k = 0; k < SEG_MAXN; ++k) {
+    for (int k = 0; k < MAXN; ++k) {
         if (k >= n) break;
         __syncthreads();
         red[threadIdx.x] = acc[k];
@@ -339,12 +341,17 @@ extern "C" int mia_pixel_linear_fwd(int dtype, const void* x, int B, int HW, int
                   "mia_pixel_linear_fwd: needs C %% 4 == 0, C <= %d, classes <= %d (got C=%d n=%d)", SEG_MAXC, SEG_MAXN, C, n);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const unsigned g = grid_for((long long)B * HW, 4096);
-    if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(pixel_linear_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)x, B, HW, C, n, Wt,
-                           bias, logits);
-    else
-        hipLaunchKernelGGL(pixel_linear_fwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x, B, HW, C, n, Wt, bias,
-                           logits);
+    auto go = [&](auto nc_tag) {
+        constexpr int NC_ = decltype(nc_tag)::value;
+        if (dtype == MIA_BF16)
+            hipLaunchKernelGGL((pixel_linear_fwd_kernel<bf16_t, NC_>), dim3(g), dim3(256), 0, s, (const bf16_t*)x, B, HW, C, n, Wt,
+                               bias, logits);
+        else
+            hipLaunchKernelGGL((pixel_linear_fwd_kernel<float, NC_>), dim3(g), dim3(256), 0, s, (const float*)x, B, HW, C, n, Wt, bias,
+                               logits);
+    };
+    if (n <= 8) go(std::integral_constant<int, 8>{});
+    else go(std::integral_constant<int, 32>{});
     MIA_CHECK_LAUNCH("mia_pixel_linear_fwd");
     return 0;
 }
@@ -357,17 +364,22 @@ extern "C" int mia_pixel_linear_bwd(int dtype, const void* x, const float* dlogi
                   "mia_pixel_linear_bwd: needs C %% 4 == 0, C <= %d, classes <= %d (got C=%d n=%d)", SEG_MAXC, SEG_MAXN, C, n);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const unsigned g = grid_for((long long)B * HW, 4096);
-    if (dtype == MIA_BF16) {
-        hipLaunchKernelGGL(pixel_linear_bwd_data_kernel<bf16_t>, dim3(g), dim3(256), 0, s, dlogits, B, HW, C, n, Wt,
-                           (bf16_t*)dx);
-        hipLaunchKernelGGL(pixel_linear_bwd_weight_kernel<bf16_t>, dim3(partial_rows), dim3(256), 0, s, (const bf16_t*)x,
-                           dlogits, B, HW, C, n, partial);
-    } else {
-        hipLaunchKernelGGL(pixel_linear_bwd_data_kernel<float>, dim3(g), dim3(256), 0, s, dlogits, B, HW, C, n, Wt,
-                           (float*)dx);
-        hipLaunchKernelGGL(pixel_linear_bwd_weight_kernel<float>, dim3(partial_rows), dim3(256), 0, s, (const float*)x,
-                           dlogits, B, HW, C, n, partial);
-    }
+    auto go = [&](auto nc_tag) {
+        constexpr int NC_ = decltype(nc_tag)::value;
+        if (dtype == MIA_BF16) {
+            hipLaunchKernelGGL((pixel_linear_bwd_data_kernel<bf16_t, NC_>), dim3(g), dim3(256), 0, s, dlogits, B, HW, C, n, Wt,
+                               (bf16_t*)dx);
+            hipLaunchKernelGGL((pixel_linear_bwd_weight_kernel<bf16_t, NC_>), dim3(partial_rows), dim3(256), 0, s, (const bf16_t*)x,
+                               dlogits, B, HW, C, n, partial);
+        } else {
+            hipLaunchKernelGGL((pixel_linear_bwd_data_kernel<float, NC_>), dim3(g), dim3(256), 0, s, dlogits, B, HW, C, n, Wt,
+                               (float*)dx);
+            hipLaunchKernelGGL((pixel_linear_bwd_weight_kernel<float, NC_>), dim3(partial_rows), dim3(256), 0, s, (const float*)x,
+                               dlogits, B, HW, C, n, partial);
+        }
+    };
+    if (n <= 8) go(std::integral_constant<int, 8>{});
+    else go(std::integral_constant<int, 32>{});
     MIA_CHECK_LAUNCH("mia_pixel_linear_bwd");
     return 0;
 }
@@ -405,41 +417,43 @@ extern "C" int mia_channel_dropout_mask(float* mask, int B, int C, float p, unsi
 // finalize (one workgroup): loss, and per-(image, class) coefficients of d score / d p = A*[t==c] + E
 // pass 2: dlogits = upstream * (ce term + softmax Jacobian applied to the overlap term)
 // ------------------------------------------------------------------------------------------------
+template <int MAXN>
 __device__ __forceinline__ void softmax_n(const float* z, int n, float* p, float& lse) {
     float m = z[0];
 #pragma unroll
-    for (int k = 1; k < SEG_MAXN; ++k)
+    for (int k = 1; k < MAXN; ++k)
         if (k < n) m = fmaxf(m, z[k]);
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < SEG_MAXN; ++k) {
+    for (int k = 0; k < MAXN; ++k) {
         p[k] = k < n ? expf(z[k] - m) : 0.f;
         s += p[k];
     }
     const float inv = 1.0f / s;
 #pragma unroll
-    for (int k = 0; k < SEG_MAXN; ++k) p[k] *= inv;
+    for (int k = 0; k < MAXN; ++k) p[k] *= inv;
     lse = m + logf(s);
 }
 
+template <int MAXN>
 __global__ __launch_bounds__(256) void seg_loss_sums_kernel(const float* logits, const long long* target, int HW, int n,
                                                             int splits, const float* cw, float* partial) {
-    __shared__ float red[4][3 * SEG_MAXN + 2];
+    __shared__ float red[4][3 * MAXN + 2];
     const int b = blockIdx.x / splits, sp = blockIdx.x % splits;
     const int per = (HW + splits - 1) / splits;
     const int p0 = sp * per, p1 = (p0 + per) < HW ? (p0 + per) : HW;
-    float I[SEG_MAXN], P[SEG_MAXN], Tn[SEG_MAXN], cen = 0.f, ced = 0.f;
+    float I[MAXN], P[MAXN], Tn[MAXN], cen = 0.f, ced = 0.f;
 #pragma unroll
-    for (int k = 0; k < SEG_MAXN; ++k) I[k] = P[k] = Tn[k] = 0.f;
+    for (int k = 0; k < MAXN; ++k) I[k] = P[k] = Tn[k] = 0.f;
     for (int p = p0 + threadIdx.x; p < p1; p += 256) {
-        float z[SEG_MAXN], pr[SEG_MAXN], lse;
+        float z[MAXN], pr[MAXN], lse;
 #pragma unroll
-        for (int k = 0; k < SEG_MAXN; ++k) z[k] = k < n ? logits[((size_t)b * n + k) * HW + p] : 0.f;
-        softmax_n(z, n, pr, lse);
+        for (int k = 0; k < MAXN; ++k) z[k] = k < n ? logits[((size_t)b * n + k) * HW + p] : 0.f;
+        softmax_n<MAXN>(z, n, pr, lse);
         const int t = (int)target[(size_t)b * HW + p];
         float zt = 0.f, wt = 1.f;
 #pragma unroll
-        for (int k = 0; k < SEG_MAXN; ++k)
+        for (int k = 0; k < MAXN; ++k)
             if (k < n) {
                 const bool hit = (k == t);
                 P[k] += pr[k];
@@ -449,7 +463,7 @@ __global__ __launch_bounds__(256) void seg_loss_sums_kernel(const float* logits,
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < SEG_MAXN; ++k) {
+    for (int k = 0; k < MAXN; ++k) {
         if (k >= n) break;
         const float a = wave_sum(I[k]), c = wave_sum(P[k]), d = wave_sum(Tn[k]);
         if (lane == 0) { red[wave][k] = a; red[wave][n + k] = c; red[wave][2 * n + k] = d; }
@@ -511,6 +525,7 @@ __global__ __launch_bounds__(256) void seg_loss_finalize_kernel(const float* par
     }
 }
 
+template <int MAXN>
 __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* logits, const long long* target, int B, int HW,
                                                            int n, const float* cw, const float* coef,
                                                            const float* upstream, float* dlogits) {
@@ -519,15 +534,15 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* logits, 
     const long long total = (long long)B * HW;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int b = (int)(i / HW), p = (int)(i % HW);
-        float z[SEG_MAXN], pr[SEG_MAXN], lse;
+        float z[MAXN], pr[MAXN], lse;
 #pragma unroll
-        for (int k = 0; k < SEG_MAXN; ++k) z[k] = k < n ? logits[((size_t)b * n + k) * HW + p] : 0.f;
-        softmax_n(z, n, pr, lse);
+        for (int k = 0; k < MAXN; ++k) z[k] = k < n ? logits[((size_t)b * n + k) * HW + p] : 0.f;
+        softmax_n<MAXN>(z, n, pr, lse);
         const int t = (int)target[i];
         const float wt = (t >= 0 && t < n) ? (cw ? cw[t] : 1.f) : 0.f;
-        float G[SEG_MAXN], dot = 0.f;
+        float G[MAXN], dot = 0.f;
 #pragma unroll
-        for (int k = 0; k < SEG_MAXN; ++k) {
+        for (int k = 0; k < MAXN; ++k) {
             G[k] = 0.f;
             if (k < n) {
                 G[k] = coef[1 + b * n + k] * (k == t ? 1.f : 0.f) + coef[1 + B * n + b * n + k];
@@ -535,7 +550,7 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* logits, 
             }
         }
 #pragma unroll
-        for (int k = 0; k < SEG_MAXN; ++k)
+        for (int k = 0; k < MAXN; ++k)
             if (k < n) {
                 const float ce_g = ces * wt * (pr[k] - (k == t ? 1.f : 0.f));
                 dlogits[((size_t)b * n + k) * HW + p] = up * (ce_g + pr[k] * (G[k] - dot));
@@ -550,8 +565,13 @@ extern "C" int mia_seg_loss_fwd(const float* logits, const long long* target, in
                   "mia_seg_loss_fwd: bad arguments");
     MIA_CHECK_ARG(n > 0 && n <= SEG_MAXN, "mia_seg_loss_fwd: classes must be 1..%d (got %d)", SEG_MAXN, n);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(seg_loss_sums_kernel, dim3(B * splits), dim3(256), 0, s, logits, target, HW, n, splits,
-                       class_weights, partial);
+    auto go = [&](auto nc_tag) {
+        constexpr int NC_ = decltype(nc_tag)::value;
+        hipLaunchKernelGGL(seg_loss_sums_kernel<NC_>, dim3(B * splits), dim3(256), 0, s, logits, target, HW, n, splits,
+                           class_weights, partial);
+    };
+    if (n <= 8) go(std::integral_constant<int, 8>{});
+    else go(std::integral_constant<int, 32>{});
     hipLaunchKernelGGL(seg_loss_finalize_kernel, dim3(1), dim3(256), 0, s, partial, B, n, splits, iou, smooth, ce_weight,
                        overlap_weight, loss, coef);
     MIA_CHECK_LAUNCH("mia_seg_loss_fwd");
@@ -563,9 +583,14 @@ extern "C" int mia_seg_loss_bwd(const float* logits, const long long* target, in
                                 void* stream) {
     MIA_CHECK_ARG(logits && target && coef && dlogits && B > 0 && HW > 0, "mia_seg_loss_bwd: bad arguments");
     MIA_CHECK_ARG(n > 0 && n <= SEG_MAXN, "mia_seg_loss_bwd: classes must be 1..%d (got %d)", SEG_MAXN, n);
-    hipLaunchKernelGGL(seg_loss_bwd_kernel, dim3(grid_for((long long)B * HW, 4096)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), logits, target, B, HW, n, class_weights, coef, upstream,
-                       dlogits);
+    auto go = [&](auto nc_tag) {
+        constexpr int NC_ = decltype(nc_tag)::value;
+        hipLaunchKernelGGL(seg_loss_bwd_kernel<NC_>, dim3(grid_for((long long)B * HW, 4096)), dim3(256), 0,
+                           reinterpret_cast<hipStream_t>(stream), logits, target, B, HW, n, class_weights, coef, upstream,
+                           dlogits);
+    };
+    if (n <= 8) go(std::integral_constant<int, 8>{});
+    else go(std::integral_constant<int, 32>{});
     MIA_CHECK_LAUNCH("mia_seg_loss_bwd");
     return 0;
 }

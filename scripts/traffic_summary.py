@@ -2,11 +2,27 @@
 device copy, then report HBM bytes per launch for each kernel of the bench step (last step's launches only)."""
 import csv, sys, re, json, collections
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
-steps_in_run = 4   # bench ran 2 warm-up + 2 timed steps
+
+def short(name):
+    return re.sub(r"\(.*$", "", re.sub(r"^void ", "", name))[:60]
+
 
 def load(path):
     rows = list(csv.DictReader(open(path)))
-    return [(re.sub(r"\(.*$", "", re.sub(r"^void ", "", r["Kernel_Name"]))[:60], float(r["Counter_Value"])) for r in rows]
+    return [(short(r["Kernel_Name"]), float(r["Counter_Value"])) for r in rows]
+
+
+def load_last_step(path):
+    """(kernel, value) of the launches of the LAST complete training step: the dispatches between the last two groups
+    of AdamW launches (set-up work such as the host-to-device copies of the parameters is not part of any step)."""
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    names = [short(r["Kernel_Name"]) for r in rows]
+    idx = [i for i, n in enumerate(names) if "adamw" in n]
+    ends = [i for k, i in enumerate(idx) if k + 1 == len(idx) or idx[k + 1] - i > 50]
+    s0, s1 = ends[-2] + 1, ends[-1] + 1
+    return [(n, float(r["Counter_Value"])) for n, r in zip(names[s0:s1], rows[s0:s1])]
+
 
 unit = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -17,14 +33,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     per = collections.defaultdict(list)
-    for k, v in load(f"{root}/traffic_{c}/bench_counter_collection.csv"):
+    for k, v in load_last_step(f"{root}/traffic_{c}/bench_counter_collection.csv"):
         per[k].append(v)
     for k, v in per.items():
-        n = len(v) // steps_in_run
-        if n == 0:
-            continue
-        last = v[-n:]
-        out.setdefault(k, {})[c] = (n, sum(last) * unit[c])
+        out.setdefault(k, {})[c] = (len(v), sum(v) * unit[c])
 tot_r = tot_w = 0.0
 print(f"{'kernel':60s} {'launches':>8s} {'read GB':>9s} {'write GB':>9s}  per step")
 for k, d in sorted(out.items(), key=lambda kv: -(kv[1].get('FETCH_SIZE', (0, 0))[1] + kv[1].get('WRITE_SIZE', (0, 0))[1]))[:24]:

@@ -144,3 +144,33 @@ def test_mha_head_bf16_close_to_fp32():
         a = m(x)
         b = m(x.bfloat16())
     assert rel(b, a) < 3e-2
+
+
+@pytest.mark.parametrize("heads", [3, 4, 16])
+def test_mha_head_other_head_counts_match_oracle(heads):
+    """num_attention_heads other than the default 8 (config.yaml:43; the reference accepts any divisor of the
+    feature width, model.py:119): head widths 128, 96 and 24 against the CPU restatement of model.py:112-175."""
+    from oracle import effnet_b3 as O
+    ref = O.MultiHeadAttentionClassifier(384, heads, 4, 0.0)
+    mine = MultiHeadAttentionClassifier(384, heads, 4, 0.0)
+    from seeding import seeded_state_dict
+    sd = seeded_state_dict(ref, 41)
+    ref.load_state_dict(sd)
+    mine.load_state_dict(sd)
+    ref.train()
+    mine = mine.cuda().train()
+    x = randn(91, 3, 384, 5, 5)
+    xr = x.clone().requires_grad_(True)
+    out_r = ref(xr)
+    xm = nhwc(x).cuda().requires_grad_(True)
+    out_m = mine(xm)
+    assert rel(out_m, out_r) < 1e-4
+    g = randn(92, *out_r.shape)
+    out_r.backward(g)
+    out_m.backward(g.cuda())
+    assert rel(xm.grad.permute(0, 3, 1, 2), xr.grad) < 1e-3
+    pr = dict(ref.named_parameters())
+    for k, p in mine.named_parameters():
+        if k.endswith("key_projection.bias") or k.endswith("key.bias"):
+            continue      # exactly zero in exact arithmetic
+        assert rel(p.grad, pr[k].grad) < 1e-3, k
