@@ -170,6 +170,7 @@ struct GemmNTParams {
     int bk_log2;    // reduction elements per LDS stage (a power of two, at most Mma<T>::BK)
     int alias_cs;   // 1: the C staging rows reuse the operand stage (one more barrier per tile, less LDS)
     int dump_off;   // byte offset of the per-thread 16-byte dump slots
+    int pro_off;    // byte offset of the prologue vectors (scale[K], shift[K]) staged once per workgroup (PRO == 2)
 };
 
 // Guarded 16-byte loads through a buffer descriptor: an offset at or beyond the descriptor's size returns zeros,
@@ -189,11 +190,11 @@ __device__ __forceinline__ raw16 buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned 
 }
 
 // One pipeline slot: the registers a thread holds for one (tile, k-stage) between its global loads and its commit.
-template <int ACH, int BCH, int VEC, bool PRO>
+template <int ACH, int BCH, int VEC, int PRO>
 struct NtSlot {
     raw16 ra[ACH], rb[BCH];
+    float pg[PRO ? ACH : 1][PRO ? VEC : 1];         // gate of each chunk row's image (row 0 only when the tile lies in one image)
     float psc[PRO ? VEC : 1], psh[PRO ? VEC : 1];   // BatchNorm scale / shift of this thread's k-chunk
-    float pg[PRO ? ACH : 1][PRO ? VEC : 1];         // gate of each chunk row's image
 };
 
 // Four waves stacked along M; each wave owns 16*MT complete rows of the BM x BN tile (BM = 64*MT, BN = 16*NT), so
@@ -202,7 +203,12 @@ struct NtSlot {
 // Pipeline: TWO stages of global loads are in flight per workgroup (slots R0/R1). When a stage is committed to
 // LDS its slot is refilled with the stage after next, so loads overlap the prologue arithmetic of the commit as
 // well as the MFMAs; with one stage in flight the kernel is bound by the load round trip.
-template <typename T, int MT, int NT, bool PRO, int DEPTH>
+// PRO: 0 no prologue; 1 prologue with its vectors read from memory per stage and one gate vector per chunk row; 2 the
+// form for large maps (row tiles inside one image, workgroups that walk many tiles): BatchNorm vectors staged in LDS
+// once, one gate vector per tile where the tile lies in one image. The load INSTRUCTIONS, not their bytes, bound the
+// prologue there: 17 buffer loads per thread and stage in form 1, 7 in form 2 (24-wide projection of the 150x150 maps:
+// 192 -> 131 us). On the small maps form 2 measured slower (start-up round trip, two images in most tiles).
+template <typename T, int MT, int NT, int PRO, int DEPTH>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
     using M_ = Mma<T>;
     using V_ = Vec16<T>;
@@ -226,6 +232,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     T* Cw = reinterpret_cast<T*>(smem + (p.alias_cs ? 0 : stage_bytes)) + wave * 16 * LDC;
     T* dump = reinterpret_cast<T*>(smem + p.dump_off + tid * 16);
+    // [2][K]: BatchNorm scale and shift (prologue variants), staged once per workgroup. Every thread needs 2*VEC of them
+    // per stage; read straight from memory that is four more buffer loads per thread and stage, and the load
+    // instructions (not their bytes) bound the prologue variants on the large maps. LDS reads do not pass that unit.
+    float* Ps = reinterpret_cast<float*>(smem + p.pro_off);
     const int M = p.M, N = p.N, K = p.K;
     // Workgroup -> (row slot, column tile). Blocks b and b+8 share an XCD (and its L2), so the column tiles of
     // one row slot are placed on consecutive slots of ONE XCD: they stream the same A rows at about the same
@@ -238,6 +248,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
     const bool has_pro = PRO && p.pscale != nullptr;
     const bool has_gate = PRO && p.gate != nullptr;
     const bool pro_silu = has_pro && p.pro_act == MIA_ACT_SILU;
+    if constexpr (PRO == 2) {
+        if (has_pro) {
+            for (int i = tid; i < K; i += 256) { Ps[i] = p.pscale[i]; Ps[K + i] = p.pshift[i]; }
+            __syncthreads();
+        }
+    }
     const int cpr_log2 = p.bk_log2 - (VEC == 8 ? 3 : 2);  // 16-byte chunks per staged row
     const int kc = (tid & ((1 << cpr_log2) - 1)) * VEC;   // this thread's k-chunk offset inside a stage
     const int rbase = tid >> cpr_log2;                    // and its first row; further chunks are rstep rows apart
@@ -263,6 +279,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
         else if (rem >= p.rows_per_img) ++q;
         return q;
     };
+    // every row of the tile starting at m0 (whose first row lies in image img0) belongs to that image
+    auto single_image = [&](int m0, int img0) -> bool {
+        const int last = m0 + BM - 1 < M ? m0 + BM - 1 : M - 1;
+        return last < (img0 + 1) * p.rows_per_img;
+    };
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, (unsigned)(((size_t)(M - 1) * p.lda + K) * sizeof(T)));
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B, (unsigned)(((size_t)(N - 1) * p.ldb + K) * sizeof(T)));
     const __amdgpu_buffer_rsrc_t rsSc = make_rsrc(p.pscale, has_pro ? (unsigned)K * 4u : 0u);
@@ -286,27 +307,39 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
             R.rb[i] = buf_load16<false>(rsB, off);
         }
         if constexpr (PRO) {
-            const unsigned koff = kin ? (unsigned)gk * 4u : MIA_BUF_OOB;
-            if (has_pro) {
+            if (has_pro && kin) {
 #pragma unroll
                 for (int e = 0; e < VEC; e += 4) {
-                    const raw16 a4 = buf_load16<false>(rsSc, koff + e * 4), b4 = buf_load16<false>(rsSh, koff + e * 4);
-                    R.psc[e] = __uint_as_float(a4.x); R.psc[e + 1] = __uint_as_float(a4.y);
-                    R.psc[e + 2] = __uint_as_float(a4.z); R.psc[e + 3] = __uint_as_float(a4.w);
-                    R.psh[e] = __uint_as_float(b4.x); R.psh[e + 1] = __uint_as_float(b4.y);
-                    R.psh[e + 2] = __uint_as_float(b4.z); R.psh[e + 3] = __uint_as_float(b4.w);
+                    if constexpr (PRO == 2) {
+                        const float4 a4 = *reinterpret_cast<const float4*>(Ps + gk + e);
+                        const float4 b4 = *reinterpret_cast<const float4*>(Ps + K + gk + e);
+                        R.psc[e] = a4.x; R.psc[e + 1] = a4.y; R.psc[e + 2] = a4.z; R.psc[e + 3] = a4.w;
+                        R.psh[e] = b4.x; R.psh[e + 1] = b4.y; R.psh[e + 2] = b4.z; R.psh[e + 3] = b4.w;
+                    } else {
+                        const raw16 a4 = buf_load16<false>(rsSc, (unsigned)(gk + e) * 4u);
+                        const raw16 b4 = buf_load16<false>(rsSh, (unsigned)(gk + e) * 4u);
+                        R.psc[e] = __uint_as_float(a4.x); R.psc[e + 1] = __uint_as_float(a4.y);
+                        R.psc[e + 2] = __uint_as_float(a4.z); R.psc[e + 3] = __uint_as_float(a4.w);
+                        R.psh[e] = __uint_as_float(b4.x); R.psh[e + 1] = __uint_as_float(b4.y);
+                        R.psh[e + 2] = __uint_as_float(b4.z); R.psh[e + 3] = __uint_as_float(b4.w);
+                    }
                 }
             }
             if (has_gate) {
+                const int img0 = PRO == 2 ? image_of(m0) : 0;
+                const bool one_img = PRO == 2 && single_image(m0, img0);
 #pragma unroll
                 for (int i = 0; i < ACH; ++i) {
-                    const int gm = m0 + rbase + i * rstep;
-                    const unsigned goff = kin ? (unsigned)(image_of(gm < M ? gm : M - 1) * K + gk) * 4u : MIA_BUF_OOB;
+                    if (PRO == 1 || i == 0 || !one_img) {
+                        const int gm = m0 + rbase + i * rstep;
+                        const int img = one_img ? img0 : image_of(gm < M ? gm : M - 1);
+                        const unsigned goff = kin ? (unsigned)(img * K + gk) * 4u : MIA_BUF_OOB;
 #pragma unroll
-                    for (int e = 0; e < VEC; e += 4) {
-                        const raw16 g4 = buf_load16<false>(rsG, goff + e * 4);
-                        R.pg[i][e] = __uint_as_float(g4.x); R.pg[i][e + 1] = __uint_as_float(g4.y);
-                        R.pg[i][e + 2] = __uint_as_float(g4.z); R.pg[i][e + 3] = __uint_as_float(g4.w);
+                        for (int e = 0; e < VEC; e += 4) {
+                            const raw16 g4 = buf_load16<false>(rsG, goff + e * 4);
+                            R.pg[i][e] = __uint_as_float(g4.x); R.pg[i][e + 1] = __uint_as_float(g4.y);
+                            R.pg[i][e + 2] = __uint_as_float(g4.z); R.pg[i][e + 3] = __uint_as_float(g4.w);
+                        }
                     }
                 }
             }
@@ -316,10 +349,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
         const int gk = k0 + kc;
         if constexpr (PRO) {
             if ((has_pro || has_gate) && gk < K) {
+                // two copies of the loop, chosen by a workgroup-uniform branch: a per-element select between pg[0] and
+                // pg[i] is folded into an indexed read of the slot, which moves the whole slot into scratch memory
+                if (PRO == 2 && has_gate && single_image(m0, image_of(m0))) {
 #pragma unroll
-                for (int i = 0; i < ACH; ++i) {
-                    const int r = rbase + i * rstep, gm = m0 + r;
-                    if (r < BM && gm < M) R.ra[i] = pro16<T>(R.ra[i], pro_silu, has_pro, has_gate, R.psc, R.psh, R.pg[i]);
+                    for (int i = 0; i < ACH; ++i) {
+                        const int r = rbase + i * rstep, gm = m0 + r;
+                        if (r < BM && gm < M) R.ra[i] = pro16<T>(R.ra[i], pro_silu, has_pro, true, R.psc, R.psh, R.pg[0]);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < ACH; ++i) {
+                        const int r = rbase + i * rstep, gm = m0 + r;
+                        if (r < BM && gm < M) R.ra[i] = pro16<T>(R.ra[i], pro_silu, has_pro, has_gate, R.psc, R.psh, R.pg[i]);
+                    }
                 }
             }
         }
@@ -497,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
     }
 }
 
-template <typename T, int MT, int NT, bool PRO>
+template <typename T, int MT, int NT, int PRO>
 static int launch_nt_(const GemmNTParams& p, int part_rows, hipStream_t stream);
 
 static int nt_stage_depth(int K, int full, int kstep) {
@@ -509,11 +552,15 @@ static int nt_stage_depth(int K, int full, int kstep) {
 
 template <typename T, int MT, int NT>
 static int launch_nt(const GemmNTParams& p, int part_rows, hipStream_t stream) {
-    if (p.pscale || p.gate) return launch_nt_<T, MT, NT, true>(p, part_rows, stream);
-    return launch_nt_<T, MT, NT, false>(p, part_rows, stream);
+    if (p.pscale || p.gate) {
+        // maps of 32x32 and more (the narrow tiles only: the wide ones never see such maps in this network)
+        if (NT <= 3 && p.rows_per_img >= 1024 && (2 * p.K * 4) <= 32 * 1024) return launch_nt_<T, MT, NT, (NT <= 3 ? 2 : 1)>(p, part_rows, stream);
+        return launch_nt_<T, MT, NT, 1>(p, part_rows, stream);
+    }
+    return launch_nt_<T, MT, NT, 0>(p, part_rows, stream);
 }
 
-template <typename T, int MT, int NT, bool PRO>
+template <typename T, int MT, int NT, int PRO>
 static int launch_nt_(const GemmNTParams& p, int part_rows, hipStream_t stream) {
     using M_ = Mma<T>;
     constexpr int BM = 64 * MT, BN = 16 * NT;
@@ -534,6 +581,8 @@ static int launch_nt_(const GemmNTParams& p, int part_rows, hipStream_t stream) 
     lds += 256 * 16;
     const int tiles_m = cdiv(p.M, BM);
     q.row_slots = p.stats ? part_rows : (tiles_m < 1024 ? tiles_m : 1024);
+    q.pro_off = lds;
+    if (PRO == 2) lds += (2 * p.K * 4 + 15) & ~15;
     dim3 grid((unsigned)(cdiv(q.row_slots, 8) * 8 * cdiv(p.N, BN)));
     // wide tiles and prologue variants are short of registers: one stage in flight; narrow plain ones stream: two
     auto kern = gemm_nt_kernel<T, MT, NT, PRO, ((NT <= 6 && !PRO) ? 2 : 1)>;
