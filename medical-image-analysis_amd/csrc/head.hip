@@ -681,6 +681,320 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* qkv, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same attention core on the matrix cores: bf16, up to 128 tokens, head widths 16/32/48/64 (the B3 head: 100
+// tokens, 8 heads of 48). One workgroup per (image, head); Q, K, V (and dO) of that head are staged in LDS as bf16,
+// row-major [token][d] and/or transposed [d][token], tokens padded with zero rows to a multiple of 16.
+//
+// Everything is computed TRANSPOSED so that no product has to leave the registers between two MFMAs:
+// v_mfma_f32_16x16x16_bf16 hands lane (c = lane%16, g = lane/16) the results D[4g..4g+3][c] and takes as B operand
+// B[k = 4g..4g+3][c] -- the same ownership. So S^T = K Q^T (rows keys, columns queries) leaves each lane with four
+// consecutive keys of one query, which after the softmax is exactly the B operand of O^T = V^T P^T; the softmax
+// reductions over keys are in-register sums plus two cross-lane steps (lanes c, c+16, c+32, c+48). The backward pass
+// does the same twice: with queries as columns for dQ^T = K^T dS^T, with keys as columns for dK^T = Q^T dS and
+// dV^T = dO^T P (dP is recomputed in each orientation: the matrix cores have the time). P (fp32, written by the
+// forward pass for the backward pass, as in the scalar kernels) is rounded to bf16 only as an MFMA operand.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float att_f32x4;
+typedef __attribute__((ext_vector_type(4))) short att_s16x4;
+#define ATT_MAXB 8   // blocks of 16 tokens
+
+__device__ __forceinline__ att_f32x4 att_mma(att_s16x4 a, att_s16x4 b, att_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ att_s16x4 att_ld4(const uint16_t* p) { return *reinterpret_cast<const att_s16x4*>(p); }
+__device__ __forceinline__ att_s16x4 att_pack4(float a, float b, float c, float d) {
+    return __builtin_bit_cast(att_s16x4, make_uint2(pack_bf16x2(v2f{a, b}), pack_bf16x2(v2f{c, d})));
+}
+__device__ __forceinline__ float att_xor_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16));
+    return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float att_xor_sum(float v) {
+    v += __shfl_xor(v, 16);
+    return v + __shfl_xor(v, 32);
+}
+
+// src: first element of the head's slice in row 0 of the image; rows are `ld` elements apart. Rows [T, TP) become zeros.
+template <int HD>
+__device__ __forceinline__ void att_stage(const uint16_t* src, int ld, int T, int TP, uint16_t* rm, int ldr, uint16_t* tr,
+                                          int ldt) {
+    constexpr int CPR = HD / 4;
+    for (int i = threadIdx.x; i < TP * CPR; i += 256) {
+        const int r = i / CPR, c4 = (i - r * CPR) * 4;
+        uint2 v = make_uint2(0u, 0u);
+        if (r < T) v = *reinterpret_cast<const uint2*>(src + (size_t)r * ld + c4);
+        if (rm) *reinterpret_cast<uint2*>(rm + r * ldr + c4) = v;
+        if (tr) {
+            tr[(c4 + 0) * ldt + r] = (uint16_t)(v.x & 0xffffu);
+            tr[(c4 + 1) * ldt + r] = (uint16_t)(v.x >> 16);
+            tr[(c4 + 2) * ldt + r] = (uint16_t)(v.y & 0xffffu);
+            tr[(c4 + 3) * ldt + r] = (uint16_t)(v.y >> 16);
+        }
+    }
+}
+
+__device__ __forceinline__ void att_store4(bf16_t* dst, const att_f32x4& v) {
+    *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v2f{v[0], v[1]}), pack_bf16x2(v2f{v[2], v[3]}));
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attention_fwd_mfma_kernel(const bf16_t* qkv, int T, int C, int heads, float scale,
+                                                                 float pdrop, unsigned long long seed,
+                                                                 const unsigned long long* seed_off, float* P, bf16_t* out) {
+    seed = seed_with_offset(seed, seed_off);
+    extern __shared__ __attribute__((aligned(16))) char att_sm[];
+    constexpr int LDR = HD + 4, DB = HD / 16;
+    const int TP = (T + 15) & ~15, NB = TP >> 4, LDT = TP + 4;
+    uint16_t* Qs = reinterpret_cast<uint16_t*>(att_sm);   // [TP][LDR]
+    uint16_t* Ks = Qs + TP * LDR;                          // [TP][LDR]
+    uint16_t* Vt = Ks + TP * LDR;                          // [HD][LDT]
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const size_t row0 = (size_t)b * T;
+    const int ld = 3 * C;
+    const uint16_t* g = reinterpret_cast<const uint16_t*>(qkv) + row0 * ld + h * HD;
+    att_stage<HD>(g, ld, T, TP, Qs, LDR, nullptr, 0);
+    att_stage<HD>(g + C, ld, T, TP, Ks, LDR, nullptr, 0);
+    att_stage<HD>(g + 2 * C, ld, T, TP, nullptr, 0, Vt, LDT);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, quad = lane >> 4;
+    const unsigned long long pbase = ((unsigned long long)b * heads + h) * T;
+    const bool vec_p = (T & 3) == 0;
+    for (int qb = wave; qb < NB; qb += 4) {
+        const int query = qb * 16 + l16;
+        const bool qok = query < T;
+        att_s16x4 qf[DB];
+#pragma unroll
+        for (int ks = 0; ks < DB; ++ks) qf[ks] = att_ld4(Qs + query * LDR + ks * 16 + quad * 4);
+        att_f32x4 s[ATT_MAXB];
+        float m = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < ATT_MAXB; ++kb) {
+            s[kb] = att_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kb < NB) {
+#pragma unroll
+                for (int ks = 0; ks < DB; ++ks)
+                    s[kb] = att_mma(att_ld4(Ks + (kb * 16 + l16) * LDR + ks * 16 + quad * 4), qf[ks], s[kb]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int key = kb * 16 + quad * 4 + i;
+                    s[kb][i] = key < T ? s[kb][i] * scale : -INFINITY;
+                    m = fmaxf(m, s[kb][i]);
+                }
+            }
+        }
+        m = att_xor_max(m);
+        float l = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < ATT_MAXB; ++kb)
+            if (kb < NB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s[kb][i] = __expf(s[kb][i] - m);
+                    l += s[kb][i];
+                }
+            }
+        l = att_xor_sum(l);
+        const float inv = 1.0f / l;
+        att_s16x4 pf[ATT_MAXB];
+#pragma unroll
+        for (int kb = 0; kb < ATT_MAXB; ++kb) {
+            pf[kb] = att_s16x4{0, 0, 0, 0};
+            if (kb < NB) {
+                const int key0 = kb * 16 + quad * 4;
+                float pv[4], pd[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pv[i] = s[kb][i] * inv;
+                    pd[i] = (qok && key0 + i < T) ? pv[i] * drop_scale(seed, (pbase + query) * T + key0 + i, pdrop) : 0.f;
+                }
+                if (qok && key0 < T) {
+                    float* prow = P + (pbase + query) * T + key0;
+                    if (vec_p) {
+                        *reinterpret_cast<float4*>(prow) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (key0 + i < T) prow[i] = pv[i];
+                    }
+                }
+                pf[kb] = att_pack4(pd[0], pd[1], pd[2], pd[3]);
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            att_f32x4 o = att_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < ATT_MAXB; ++kb)
+                if (kb < NB) o = att_mma(att_ld4(Vt + (db * 16 + l16) * LDT + kb * 16 + quad * 4), pf[kb], o);
+            if (qok) att_store4(out + (row0 + query) * C + h * HD + db * 16 + quad * 4, o);
+        }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t* qkv, const float* P, const bf16_t* dout,
+                                                                 const bf16_t* out, int T, int C, int heads, float scale,
+                                                                 float pdrop, unsigned long long seed,
+                                                                 const unsigned long long* seed_off, bf16_t* dqkv) {
+    seed = seed_with_offset(seed, seed_off);
+    extern __shared__ __attribute__((aligned(16))) char att_sm[];
+    constexpr int LDR = HD + 4, DB = HD / 16;
+    const int TP = (T + 15) & ~15, NB = TP >> 4, LDT = TP + 4;
+    uint16_t* Vs = reinterpret_cast<uint16_t*>(att_sm);   // [TP][LDR]
+    uint16_t* Gs = Vs + TP * LDR;                          // [TP][LDR]  dO
+    uint16_t* Kt = Gs + TP * LDR;                          // [HD][LDT]
+    uint16_t* Qt = Kt + HD * LDT;                          // [HD][LDT]
+    uint16_t* Gt = Qt + HD * LDT;                          // [HD][LDT]  dO^T
+    float* Ds = reinterpret_cast<float*>(Gt + HD * LDT);   // [TP]  D_r = dO_r . O_r
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const size_t row0 = (size_t)b * T;
+    const int ld = 3 * C;
+    const uint16_t* g = reinterpret_cast<const uint16_t*>(qkv) + row0 * ld + h * HD;
+    const uint16_t* go = reinterpret_cast<const uint16_t*>(dout) + row0 * C + h * HD;
+    att_stage<HD>(g, ld, T, TP, nullptr, 0, Qt, LDT);
+    att_stage<HD>(g + C, ld, T, TP, nullptr, 0, Kt, LDT);
+    att_stage<HD>(g + 2 * C, ld, T, TP, Vs, LDR, nullptr, 0);
+    att_stage<HD>(go, C, T, TP, Gs, LDR, Gt, LDT);
+    for (int r = threadIdx.x; r < TP; r += 256) {
+        float d = 0.f;
+        if (r < T) {
+            const bf16_t* a = dout + (row0 + r) * C + h * HD;
+            const bf16_t* o = out + (row0 + r) * C + h * HD;
+#pragma unroll
+            for (int c = 0; c < HD; c += 4) {
+                const f22 x = load22<bf16_t>(a + c), y = load22<bf16_t>(o + c);
+                d += x.lo.x * y.lo.x + x.lo.y * y.lo.y + x.hi.x * y.hi.x + x.hi.y * y.hi.y;
+            }
+        }
+        Ds[r] = d;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, quad = lane >> 4;
+    const unsigned long long pbase = ((unsigned long long)b * heads + h) * T;
+    const bool vec_p = (T & 3) == 0;
+    uint16_t* dq_out = reinterpret_cast<uint16_t*>(dqkv) + row0 * ld + h * HD;
+
+    // queries as columns: dP^T = V dO^T, dS^T = P^T o (dP^T - D) * scale, dQ^T = K^T dS^T
+    for (int qb = wave; qb < NB; qb += 4) {
+        const int query = qb * 16 + l16;
+        const bool qok = query < T;
+        const float Dq = Ds[query];
+        att_s16x4 gf[DB];
+#pragma unroll
+        for (int ks = 0; ks < DB; ++ks) gf[ks] = att_ld4(Gs + query * LDR + ks * 16 + quad * 4);
+        att_s16x4 dsf[ATT_MAXB];
+#pragma unroll
+        for (int kb = 0; kb < ATT_MAXB; ++kb) {
+            dsf[kb] = att_s16x4{0, 0, 0, 0};
+            if (kb < NB) {
+                att_f32x4 dp = att_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < DB; ++ks)
+                    dp = att_mma(att_ld4(Vs + (kb * 16 + l16) * LDR + ks * 16 + quad * 4), gf[ks], dp);
+                const int key0 = kb * 16 + quad * 4;
+                float pv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (qok && key0 < T) {
+                    const float* prow = P + (pbase + query) * T + key0;
+                    if (vec_p) {
+                        const float4 t = *reinterpret_cast<const float4*>(prow);
+                        pv[0] = t.x; pv[1] = t.y; pv[2] = t.z; pv[3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (key0 + i < T) pv[i] = prow[i];
+                    }
+                }
+                float ds[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float dsc = (qok && key0 + i < T) ? drop_scale(seed, (pbase + query) * T + key0 + i, pdrop) : 0.f;
+                    ds[i] = pv[i] * (dp[i] * dsc - Dq) * scale;
+                }
+                dsf[kb] = att_pack4(ds[0], ds[1], ds[2], ds[3]);
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            att_f32x4 acc = att_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < ATT_MAXB; ++kb)
+                if (kb < NB) acc = att_mma(att_ld4(Kt + (db * 16 + l16) * LDT + kb * 16 + quad * 4), dsf[kb], acc);
+            if (qok) att_store4(reinterpret_cast<bf16_t*>(dq_out + (size_t)query * ld + db * 16 + quad * 4), acc);
+        }
+    }
+
+    // keys as columns: dP = dO V^T, dS = P o (dP - D) * scale, dK^T = Q^T dS, dV^T = dO^T P
+    for (int kb = wave; kb < NB; kb += 4) {
+        const int key = kb * 16 + l16;
+        const bool kok = key < T;
+        att_s16x4 vf[DB];
+#pragma unroll
+        for (int ks = 0; ks < DB; ++ks) vf[ks] = att_ld4(Vs + key * LDR + ks * 16 + quad * 4);
+        att_s16x4 dsf[ATT_MAXB], pdf[ATT_MAXB];
+#pragma unroll
+        for (int qb = 0; qb < ATT_MAXB; ++qb) {
+            dsf[qb] = att_s16x4{0, 0, 0, 0};
+            pdf[qb] = att_s16x4{0, 0, 0, 0};
+            if (qb < NB) {
+                att_f32x4 dp = att_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < DB; ++ks)
+                    dp = att_mma(att_ld4(Gs + (qb * 16 + l16) * LDR + ks * 16 + quad * 4), vf[ks], dp);
+                float ds[4], pd[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int q = qb * 16 + quad * 4 + i;
+                    const bool ok = kok && q < T;
+                    const float pv = ok ? P[(pbase + q) * T + key] : 0.f;
+                    const float dsc = ok ? drop_scale(seed, (pbase + q) * T + key, pdrop) : 0.f;
+                    ds[i] = pv * (dp[i] * dsc - Ds[q]) * scale;
+                    pd[i] = pv * dsc;
+                }
+                dsf[qb] = att_pack4(ds[0], ds[1], ds[2], ds[3]);
+                pdf[qb] = att_pack4(pd[0], pd[1], pd[2], pd[3]);
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            att_f32x4 dk = att_f32x4{0.f, 0.f, 0.f, 0.f}, dv = att_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qb = 0; qb < ATT_MAXB; ++qb)
+                if (qb < NB) {
+                    dk = att_mma(att_ld4(Qt + (db * 16 + l16) * LDT + qb * 16 + quad * 4), dsf[qb], dk);
+                    dv = att_mma(att_ld4(Gt + (db * 16 + l16) * LDT + qb * 16 + quad * 4), pdf[qb], dv);
+                }
+            if (kok) {
+                att_store4(reinterpret_cast<bf16_t*>(dq_out + (size_t)key * ld + C + db * 16 + quad * 4), dk);
+                att_store4(reinterpret_cast<bf16_t*>(dq_out + (size_t)key * ld + 2 * C + db * 16 + quad * 4), dv);
+            }
+        }
+    }
+}
+
+static bool attention_use_mfma(int dtype, int HW, int HD) {
+    return dtype == MIA_BF16 && HW <= 16 * ATT_MAXB && HD % 16 == 0 && HD <= 64;
+}
+
+template <int HD>
+static void launch_attention_mfma_(bool fwd, const void* qkv, const float* P, const void* dout, const void* o, int B, int HW,
+                                   int C, int heads, float scale, float pdrop, unsigned long long seed,
+                                   const unsigned long long* seed_off, float* Pout, void* out, hipStream_t s) {
+    const int TP = (HW + 15) & ~15;
+    const size_t rm = (size_t)TP * (HD + 4) * 2, tr = (size_t)HD * (TP + 4) * 2;
+    const size_t lds = fwd ? 2 * rm + tr : 2 * rm + 3 * tr + (size_t)TP * 4;
+    dim3 grid(B * heads);
+    if (fwd) {
+        auto k = attention_fwd_mfma_kernel<HD>;
+        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const bf16_t*)qkv, HW, C, heads, scale, pdrop, seed, seed_off, Pout, (bf16_t*)out);
+    } else {
+        auto k = attention_bwd_mfma_kernel<HD>;
+        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const bf16_t*)qkv, P, (const bf16_t*)dout, (const bf16_t*)o, HW, C, heads, scale, pdrop, seed, seed_off, (bf16_t*)out);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // pooled features -> (LayerNorm) -> dropout. One wave per image row. in_part [B][S][C] holds sums over H*W.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pool_ln_dropout_fwd_kernel(const float* in_part, int B, int S, int C,
@@ -1035,6 +1349,15 @@ static int launch_attention(bool fwd, const void* qkv, const float* P, const voi
                             hipStream_t s) {
     const int HD = C / heads;
     const float scale = 1.0f / sqrtf((float)HD);
+    if (attention_use_mfma(sizeof(T) == 2 ? MIA_BF16 : MIA_F32, HW, HD)) {
+        switch (HD) {
+            case 16: launch_attention_mfma_<16>(fwd, qkv, P, dout, o, B, HW, C, heads, scale, pdrop, seed, seed_off, Pout, out, s); break;
+            case 32: launch_attention_mfma_<32>(fwd, qkv, P, dout, o, B, HW, C, heads, scale, pdrop, seed, seed_off, Pout, out, s); break;
+            case 48: launch_attention_mfma_<48>(fwd, qkv, P, dout, o, B, HW, C, heads, scale, pdrop, seed, seed_off, Pout, out, s); break;
+            default: launch_attention_mfma_<64>(fwd, qkv, P, dout, o, B, HW, C, heads, scale, pdrop, seed, seed_off, Pout, out, s); break;
+        }
+        return 0;
+    }
     const size_t lds = ((size_t)2 * HW * HD + (fwd ? 0 : HW + (size_t)ATT_JC * HW)) * 4;
     dim3 grid(B * heads);
 #define MIA_ATT(HD_)                                                                                                  \

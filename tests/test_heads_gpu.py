@@ -174,3 +174,26 @@ def test_mha_head_other_head_counts_match_oracle(heads):
         if k.endswith("key_projection.bias") or k.endswith("key.bias"):
             continue      # exactly zero in exact arithmetic
         assert rel(p.grad, pr[k].grad) < 1e-3, k
+
+
+@pytest.mark.parametrize("tokens,heads,hd,pdrop", [(100, 8, 48, 0.0), (100, 8, 48, 0.1), (25, 4, 16, 0.1), (9, 2, 32, 0.0),
+                                                   (128, 2, 64, 0.1), (49, 3, 48, 0.0), (16, 2, 16, 0.1)])
+def test_attention_matrix_core_path_matches_fp32_kernels(tokens, heads, hd, pdrop):
+    """bf16 attention with up to 128 tokens and head widths 16/32/48/64 runs on the matrix cores; fp32 runs the
+    per-thread kernels. Same bf16-rounded q, k, v and output gradient into both, same dropout seed (the masks are a
+    function of seed and element index, so they coincide): the results differ only by the bf16 rounding of P and dS
+    as MFMA operands and of the outputs. Stated tolerance: 1 % of each tensor's largest magnitude (bf16 has 8 bits)."""
+    B, C = 3, heads * hd
+    qkv = (randn(51, B * tokens, 3 * C) * 0.7).bfloat16().cuda()
+    g = randn(52, B * tokens, C).bfloat16().cuda()
+    res = {}
+    for dt in (torch.bfloat16, torch.float32):
+        x = qkv.detach().to(dt).clone().requires_grad_(True)
+        out = head_ops.AttentionFn.apply(x, B, tokens, C, heads, pdrop, 777)
+        out.backward(g.to(dt))
+        res[dt] = (out.detach().float(), x.grad.float())
+    assert rel(res[torch.bfloat16][0], res[torch.float32][0]) < 1e-2
+    for i, name in enumerate(("dq", "dk", "dv")):
+        a = res[torch.bfloat16][1][:, i * C:(i + 1) * C]
+        b = res[torch.float32][1][:, i * C:(i + 1) * C]
+        assert rel(a, b) < 1e-2, name
