@@ -611,12 +611,16 @@ static int dispatch_nt(const GemmNTParams& p, int part_rows, hipStream_t stream)
     // 128-wide column tiles of 128 rows were measured faster: 1392-wide expansion 37 -> 31 us, 232-wide projection 61 -> 52 us
     if (best == 240 && p.M <= 16384) best = 128;
     // few row tiles: halve the tile height so that the grid still covers the chip
-    const bool small_m = (long long)cdiv(p.M, 128) * cdiv(p.N, best) < 384 && p.M > 64;
+    const long long tiles128 = (long long)cdiv(p.M, 128) * cdiv(p.N, best);
+    const bool small_m = tiles128 < 384 && p.M > 64;
+    // the 144-wide tile reads 9 B fragments per A fragment from LDS at 64 rows, 4.5 at 128: the taller tile wins from
+    // 256 tiles on (19x19 maps, 136 <-> 816 channels: data gradient 44.7 -> 36.3 us, projection 60.1 -> 56.4 us)
+    const bool small_m144 = tiles128 < 256 && p.M > 64;
     switch (best) {
         case 32: return launch_nt<T, 2, 2>(p, part_rows, stream);
         case 48: return launch_nt<T, 2, 3>(p, part_rows, stream);
         case 96: return small_m ? launch_nt<T, 1, 6>(p, part_rows, stream) : launch_nt<T, 2, 6>(p, part_rows, stream);
-        case 144: return small_m ? launch_nt<T, 1, 9>(p, part_rows, stream) : launch_nt<T, 2, 9>(p, part_rows, stream);
+        case 144: return small_m144 ? launch_nt<T, 1, 9>(p, part_rows, stream) : launch_nt<T, 2, 9>(p, part_rows, stream);
         case 192:
             // 128-row tiles of this width with the prologue's registers would spill
             return (small_m || p.pscale || p.gate) ? launch_nt<T, 1, 12>(p, part_rows, stream)

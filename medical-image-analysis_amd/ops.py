@@ -82,6 +82,7 @@ class Side:
         when Side.enabled is off, or when one of the parameters already holds a gradient (autograd would add to it on
         the main stream at once)."""
     enabled = True
+    depth = 0          # > 0 while launches go to a side stream (inside a `with Side(...)` block)
     _streams = {}      # (device index, main stream id) -> side stream
     _pending = {}      # (device index, main stream id) -> (main, side) with side work the main stream has not waited for
 
@@ -109,9 +110,11 @@ class Side:
         Side._pending[self.key] = (self.main, self.side)
         self._ctx = torch.cuda.stream(self.side)
         self._ctx.__enter__()
+        Side.depth += 1
         return self
 
     def __exit__(self, *exc):
+        Side.depth -= 1
         self._ctx.__exit__(*exc)
         try:
             torch.autograd.Variable._execution_engine.queue_callback(Side.sync)
@@ -147,7 +150,7 @@ class KernelTimer:
     kernels are launched on). Off by default; bench.py turns it on for the family it prices against the
     roofline. `bytes` is the algorithmic HBM traffic of the launch (operands read once, results written once)."""
     families = None   # None = off, else a set of family names
-    records = {}      # family -> list of (start_event, end_event, bytes)
+    records = {}      # family -> list of (start_event, end_event, bytes, launched on the side stream)
 
     @classmethod
     def start(cls, families):
@@ -155,12 +158,12 @@ class KernelTimer:
 
     @classmethod
     def stop(cls):
-        """-> {family: (launches, total_ms, total_bytes)}; synchronises."""
+        """-> {family: (launches, total_ms, total_bytes, launches on the side stream)}; synchronises."""
         torch.cuda.synchronize()
         out = {}
         for fam, recs in cls.records.items():
-            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
-            out[fam] = (len(recs), ms, sum(n for _, _, n in recs))
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            out[fam] = (len(recs), ms, sum(r[2] for r in recs), sum(1 for r in recs if r[3]))
         cls.families, cls.records = None, {}
         return out
 
@@ -172,7 +175,7 @@ def _launch(family, nbytes, fn, *args):
     a.record()
     r = fn(*args)
     b.record()
-    KernelTimer.records.setdefault(family, []).append((a, b, nbytes))
+    KernelTimer.records.setdefault(family, []).append((a, b, nbytes, Side.depth > 0))
     return r
 
 
