@@ -10,11 +10,11 @@ timeout -k 10 300 python -u bench.py --kernel-table > gpurun_out/$TAG/bench.json
 tail -1 gpurun_out/$TAG/bench.json | cut -c1-400
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/stats -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/$TAG/stats.log 2>&1
-cd $R && python scripts/trace_summary.py $(ls gpurun_out/$TAG/stats/*/*kernel_trace.csv gpurun_out/$TAG/stats/*kernel_trace.csv 2>/dev/null | head -1) 25 > gpurun_out/$TAG/kernel_summary.txt 2>&1 || true
+cd $R && python scripts/trace_summary.py $(ls gpurun_out/$TAG/stats/*/*kernel_trace.csv gpurun_out/$TAG/stats/*kernel_trace.csv 2>/dev/null | head -1) 27 > gpurun_out/$TAG/kernel_summary.txt 2>&1 || true
 # the same step with the weight-gradient stream off: every kernel runs alone, so its duration is its own
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/stats_solo -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-fork > $R/gpurun_out/$TAG/stats_solo.log 2>&1
-cd $R && python scripts/trace_summary.py $(ls gpurun_out/$TAG/stats_solo/*/*kernel_trace.csv gpurun_out/$TAG/stats_solo/*kernel_trace.csv 2>/dev/null | head -1) 25 > gpurun_out/$TAG/kernel_summary_solo.txt 2>&1 || true
+cd $R && python scripts/trace_summary.py $(ls gpurun_out/$TAG/stats_solo/*/*kernel_trace.csv gpurun_out/$TAG/stats_solo/*kernel_trace.csv 2>/dev/null | head -1) 27 > gpurun_out/$TAG/kernel_summary_solo.txt 2>&1 || true
 if [ "$2" == "traffic" ]; then
   cd /tmp
   for C in FETCH_SIZE WRITE_SIZE; do
