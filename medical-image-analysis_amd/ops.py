@@ -82,9 +82,11 @@ class Side:
         when Side.enabled is off, or when one of the parameters already holds a gradient (autograd would add to it on
         the main stream at once)."""
     enabled = True
+    MIN_WORK = 8_000_000   # elements of the block's expanded tensor below which its weight gradients stay on the main stream
     depth = 0          # > 0 while launches go to a side stream (inside a `with Side(...)` block)
-    _streams = {}      # (device index, main stream id) -> side stream
+    _streams = {}      # (device index, main stream id) -> (side stream, fork event)
     _pending = {}      # (device index, main stream id) -> (main, side) with side work the main stream has not waited for
+    _callback_task = -1        # autograd graph task that already has the join queued (one callback per backward pass)
 
     @classmethod
     def usable(cls, params=()) -> bool:
@@ -95,31 +97,36 @@ class Side:
     def __init__(self, device, reads=()):
         self.main = torch.cuda.current_stream(device)
         self.key = (device.index, self.main.cuda_stream)
-        side = Side._streams.get(self.key)
-        if side is None:
-            side = torch.cuda.Stream(device=device)
-            Side._streams[self.key] = side
-        self.side = side
+        ent = Side._streams.get(self.key)
+        if ent is None:
+            # one event per stream pair, re-recorded at every fork (Stream.wait_stream would create and destroy one
+            # each time: a backward pass forks about a hundred times)
+            ent = (torch.cuda.Stream(device=device), torch.cuda.Event())
+            Side._streams[self.key] = ent
+        self.side, self.fork = ent
         self.reads = reads
 
     def __enter__(self):
-        self.side.wait_stream(self.main)
+        self.fork.record(self.main)
+        self.side.wait_event(self.fork)
         for t in self.reads:
             if t is not None:
                 t.record_stream(self.side)
         Side._pending[self.key] = (self.main, self.side)
-        self._ctx = torch.cuda.stream(self.side)
-        self._ctx.__enter__()
+        # set_stream directly: cheaper on the host than the torch.cuda.stream() context manager
+        torch.cuda.set_stream(self.side)
         Side.depth += 1
         return self
 
     def __exit__(self, *exc):
         Side.depth -= 1
-        self._ctx.__exit__(*exc)
-        try:
+        torch.cuda.set_stream(self.main)
+        task = torch._C._current_graph_task_id()
+        if task < 0:
+            Side.sync()         # not inside a backward pass: nothing will call back, so join here
+        elif task != Side._callback_task:
             torch.autograd.Variable._execution_engine.queue_callback(Side.sync)
-        except RuntimeError:
-            Side.sync()     # not inside a backward pass: nothing will call back, so join here
+            Side._callback_task = task
         return False
 
     @classmethod
@@ -141,7 +148,12 @@ class _Inline:
         return False
 
 
-def side_scope(device, params, reads):
+def side_scope(device, params, reads, work=None):
+    """work: elements the side kernels stream (None = unknown: fork). Below Side.MIN_WORK the fork is not worth its
+    hand-over: an event record + wait each way costs the host ~10 us and the device a queue switch, which kernels of
+    a few microseconds cannot hide (eager step at batch 8: 20.0 ms forking everywhere, 15.6 ms on one stream)."""
+    if work is not None and work < Side.MIN_WORK:
+        return _Inline()
     return Side(device, reads) if Side.usable(params) else _Inline()
 
 
@@ -622,7 +634,8 @@ class MBConvFn(torch.autograd.Function):
         dy3 = affine2(dout, c3[2], c3[4], y=y3, b=c3[3]).view(M2, Co)
         # ---- projection: weight and data gradients ----
         wparams = (w_exp, w_dw, w_proj)
-        with side_scope(x.device, wparams, (dy3, y2, st2, gate)):
+        work = M2 * Cm
+        with side_scope(x.device, wparams, (dy3, y2, st2, gate), work):
             dwproj = gemm_tn(dy3, y2.view(M2, Cm), pscale=st2[0], pshift=st2[1], pro_act=ACT_SILU, gate=gate,
                              rows_per_img=OH * OW)
         dz, _ = gemm_nt(dy3, ctx.wprojT)
@@ -631,7 +644,7 @@ class MBConvFn(torch.autograd.Function):
         sums = se_bwd_sums(y2, dz, st2)
         wr, weT = _w2d(w_ser), ctx.weT
         dpool, dpre2, dpre1 = se_gate_bwd(sums[0], OH * OW, wr, weT, gate, hpre, pooled)
-        with side_scope(x.device, wparams + (w_ser, w_see), (dpre2, dpre1, pooled, hpre)):
+        with side_scope(x.device, wparams + (w_ser, w_see), (dpre2, dpre1, pooled, hpre), work):
             dwr, dbr, dwe, dbe = se_param_grad(dpre2, dpre1, pooled, hpre)
         # ---- bn after depthwise (+SiLU): its reductions come from the same per-image sums ----
         c2 = bn_finalize_bwd(se_bn_combine(sums, gate, dpool), M2, g2, st2, training)
@@ -640,7 +653,7 @@ class MBConvFn(torch.autograd.Function):
         rows_in = part_rows(B * ((H * W + 127) // 128))
         if cfg.kind == "ir":
             # depthwise data gradient with fused silu' and bn1 partials
-            with side_scope(x.device, wparams, (y1, dy2, st1)):
+            with side_scope(x.device, wparams, (y1, dy2, st1), work):
                 ddw = dwconv_bwd_weight(y1, dy2, k, s, pscale=st1[0], pshift=st1[1])
             g1t, part = dwconv_bwd_data(dy2, wdw, k, s, (H, W), yfwd=y1, escale=st1[0], eshift=st1[1], emean=st1[2],
                                         erstd=st1[3], stats_rows=rows_in)
@@ -650,7 +663,7 @@ class MBConvFn(torch.autograd.Function):
                 # dy1 = ca*g + cb*y1 + cd is never formed: both products that consume it are linear in it
                 g2d = g1t.view(M, Cm)
                 wcaT, S, r = bn_lin_prep(ctx.wexp, c1)
-                with side_scope(x.device, wparams, (g1t, x, c1, ctx.wexp)):
+                with side_scope(x.device, wparams, (g1t, x, c1, ctx.wexp), work):
                     t1 = gemm_tn(g2d, x2d)
                     G = gemm_tn(x2d, x2d)
                     cs = img_colsum(x, None, None, None, ACT_NONE).sum((0, 1))
@@ -659,14 +672,14 @@ class MBConvFn(torch.autograd.Function):
                 dx, _ = gemm_nt(g2d, wcaT, add=xs)
             else:
                 dy1 = affine2(g1t, c1[2], c1[4], y=y1, b=c1[3], out=g1t).view(M, Cm)
-                with side_scope(x.device, wparams, (dy1, x)):
+                with side_scope(x.device, wparams, (dy1, x), work):
                     dwexp = gemm_tn(dy1, x2d)
                 dx, _ = gemm_nt(dy1, ctx.wexpT, add=dout.view(M, Cin) if cfg.has_skip else None)
             dx = dx.view(B, H, W, Cin)
             return (dx, dwexp.view_as(w_exp), c1[0], c1[1], ddw, c2[0], c2[1], dwr.view_as(w_ser), dbr,
                     dwe.view_as(w_see), dbe, dwproj.view_as(w_proj), c3[0], c3[1], None)
         # ds block: the depthwise conv reads the block input directly
-        with side_scope(x.device, wparams, (x, dy2)):
+        with side_scope(x.device, wparams, (x, dy2), work):
             ddw = dwconv_bwd_weight(x, dy2, k, s)
         dx, _ = dwconv_bwd_data(dy2, wdw, k, s, (H, W))
         if cfg.has_skip:

@@ -25,3 +25,17 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _fork_every_block(request):
+    """GPU tests run small models: let every block fork its weight gradients to the second stream (production skips
+    the fork for blocks too small to repay it), so that the two-stream path is what the parity tests exercise."""
+    if "gpu" not in request.keywords:
+        yield
+        return
+    from mia_amd import ops
+    old = ops.Side.MIN_WORK
+    ops.Side.MIN_WORK = 0
+    yield
+    ops.Side.MIN_WORK = old
