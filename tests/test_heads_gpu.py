@@ -177,7 +177,7 @@ def test_mha_head_other_head_counts_match_oracle(heads):
 
 
 @pytest.mark.parametrize("tokens,heads,hd,pdrop", [(100, 8, 48, 0.0), (100, 8, 48, 0.1), (25, 4, 16, 0.1), (9, 2, 32, 0.0),
-                                                   (128, 2, 64, 0.1), (49, 3, 48, 0.0), (16, 2, 16, 0.1)])
+                                                   (128, 2, 64, 0.1), (49, 3, 48, 0.0), (16, 2, 16, 0.1), (4, 8, 48, 0.1), (1, 8, 48, 0.0)])
 def test_attention_matrix_core_path_matches_fp32_kernels(tokens, heads, hd, pdrop):
     """bf16 attention with up to 128 tokens and head widths 16/32/48/64 runs on the matrix cores; fp32 runs the
     per-thread kernels. Same bf16-rounded q, k, v and output gradient into both, same dropout seed (the masks are a
@@ -196,4 +196,7 @@ def test_attention_matrix_core_path_matches_fp32_kernels(tokens, heads, hd, pdro
     for i, name in enumerate(("dq", "dk", "dv")):
         a = res[torch.bfloat16][1][:, i * C:(i + 1) * C]
         b = res[torch.float32][1][:, i * C:(i + 1) * C]
-        assert rel(a, b) < 1e-2, name
+        # with one token dq and dk are exactly zero in exact arithmetic (softmax of one score): both sides hold rounding
+        # noise there, so the yardstick is never smaller than a thousandth of the incoming gradient
+        scale = max(b.abs().max().item(), 1e-3 * g.float().abs().max().item())
+        assert (a - b).abs().max().item() < 1e-2 * scale, name
