@@ -46,6 +46,9 @@ class GraphedForward:
                              f"got {tuple(x.shape)} {x.dtype}")
         if self.model.training:
             raise RuntimeError("the model was switched to train mode after capture")
+        refresh = getattr(self.model, "refresh_inference_weights", None)
+        if refresh is not None:
+            refresh()      # BatchNorm-folded weights are kept outside the captured launches: rewritten in place when stale
         self.static_in.copy_(x, non_blocking=True)
         self.graph.replay()
         return self.static_out.clone() if copy_out else self.static_out

@@ -80,6 +80,11 @@ class FoundationModel(nn.Module):
         self.backbone.compute_dtype = dtype if isinstance(dtype, torch.dtype) else _DTYPES[dtype]
         return self
 
+    def refresh_inference_weights(self):
+        """Eval-mode inference keeps BatchNorm-folded copies of the trunk's 1x1 convolution weights; they refresh
+        themselves on every eager forward, and a HIP-graph replay (graphs.GraphedForward) calls this first."""
+        self.backbone.refresh_inference_weights()
+
     def _check_device(self, x):
         p = next(self.parameters())
         if not x.is_cuda or not p.is_cuda:

@@ -34,6 +34,8 @@ class _Cfg:
 # per-trunk launch tables of the batched weight cast (ctypes arrays: kept off the module so that copying or pickling a
 # model never meets them)
 _CASTERS = weakref.WeakKeyDictionary()
+# per-trunk BatchNorm-folded inference weights: (key of data pointers and versions of every source tensor, tensors)
+_FOLDED = weakref.WeakKeyDictionary()
 
 
 class SqueezeExcite(nn.Module):
@@ -150,7 +152,128 @@ class EfficientNetB3Features(nn.Module):
             out.append(d)
         return out
 
+    # ------------------------------------------------------------------------------------------------
+    # Inference (eval mode, no autograd): BatchNorm is a fixed per-channel affine, so it is folded into the 1x1
+    # convolution in front of it (weights scaled per output channel, shift as the GEMM bias) and SiLU / the residual
+    # run in that GEMM's epilogue: the expansion writes the activated tensor, the projection writes the block output.
+    # Per block: expansion GEMM, depthwise conv, pooled sums, SE gate, projection GEMM; no BatchNorm launches, no
+    # separate apply/residual pass, no prologue arithmetic in the depthwise kernel. (In training the statistics of a
+    # layer exist only after its convolution has finished, so there the normalisation rides in the CONSUMER's prologue.)
+    # ------------------------------------------------------------------------------------------------
+    def _fold_tensors(self):
+        tens = [self.conv_stem.weight]
+        mods = [self.bn1] + [m for stage in self.blocks for blk in stage for m in blk.modules()
+                             if isinstance(m, (nn.Conv2d, nn.BatchNorm2d))]
+        for m in mods:
+            if isinstance(m, nn.BatchNorm2d):
+                tens += [m.weight, m.bias, m.running_mean, m.running_var]
+            else:
+                tens += [m.weight] + ([m.bias] if m.bias is not None else [])
+        return tens
+
+    def _build_folded(self):
+        dt = self.compute_dtype
+
+        def fold(bn):
+            sc = (bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps))
+            return sc.contiguous(), (bn.bias.detach().float() - bn.running_mean.float() * sc).contiguous()
+
+        def scaled(w2d, sc, pad=None):
+            w = w2d.detach().float() * sc[:, None]
+            if pad and pad > w.shape[1]:
+                w = torch.nn.functional.pad(w, (0, pad - w.shape[1]))
+            return w.to(dt).contiguous()
+
+        w2 = ops._w2d
+        s0, b0 = fold(self.bn1)
+        out = [scaled(w2(self.conv_stem.weight), s0, 32), b0]
+        for stage in self.blocks:
+            for blk in stage:
+                if blk.kind == "ir":
+                    s1, b1 = fold(blk.bn1)
+                    s2, b2 = fold(blk.bn2)
+                    s3, b3 = fold(blk.bn3)
+                    wexp, wproj = scaled(w2(blk.conv_pw.weight), s1), scaled(w2(blk.conv_pwl.weight), s3)
+                else:
+                    wexp, b1 = None, None
+                    s2, b2 = fold(blk.bn1)
+                    s3, b3 = fold(blk.bn2)
+                    wproj = scaled(w2(blk.conv_pw.weight), s3)
+                cm = blk.conv_dw.weight.shape[0]
+                out += [wexp, b1, s2, b2, wproj, b3,
+                        blk.conv_dw.weight.detach().float().reshape(cm, blk.k * blk.k).contiguous(),
+                        w2(blk.se.conv_reduce.weight).detach().float().contiguous(),
+                        blk.se.conv_reduce.bias.detach().float().contiguous(),
+                        w2(blk.se.conv_expand.weight).detach().float().t().contiguous(),
+                        blk.se.conv_expand.bias.detach().float().contiguous()]
+        return out
+
+    def _folded(self):
+        """-> flat list of inference tensors: stem (weights, bias), then per block (wexp, b1, s2, b2, wproj, b3, wdw,
+        wr, br, weT, be). Rebuilt when a source tensor was written or replaced; a rebuild writes INTO the tensors
+        handed out before (same addresses), so a captured HIP graph that reads them follows weight updates."""
+        cached = _FOLDED.get(self)
+        tens = cached[2] if cached is not None else self._fold_tensors()
+        # in-place writes bump the version counters; module.to()/cuda() replace the storages and come through _apply
+        try:
+            key = (self.compute_dtype, tuple([t._version for t in tens]), tens[0].data_ptr(), tens[-1].data_ptr())
+        except RuntimeError:     # inference tensors keep no version counter: nothing to compare, fold again
+            return self._build_folded()
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        fresh = self._build_folded()
+        if cached is not None and cached[0][0] == key[0] and len(cached[1]) == len(fresh) and all(
+                (a is None) == (b is None) and (a is None or (a.shape == b.shape and a.device == b.device))
+                for a, b in zip(cached[1], fresh)):
+            for a, b in zip(cached[1], fresh):
+                if a is not None:
+                    a.copy_(b)
+            fresh = cached[1]
+        _FOLDED[self] = (key, fresh, tens)
+        return fresh
+
+    def _apply(self, fn, *args, **kwargs):
+        _FOLDED.pop(self, None)      # .to() / .cuda() / .float(): the folded copies refer to the old storages
+        return super()._apply(fn, *args, **kwargs)
+
+    def refresh_inference_weights(self):
+        """Bring the BatchNorm-folded inference weights up to date (a no-op when nothing changed). HIP-graph replays
+        of the eval forward call this first: the fold is host-side bookkeeping, not part of the captured launches."""
+        if not self.training:
+            self._folded()
+
+    def _infer_nhwc(self, x) -> List[torch.Tensor]:
+        fw = self._folded()
+        B = x.shape[0]
+        col, OH, OW = ops.stem_im2col(x.contiguous().float(), self.compute_dtype)
+        h, _ = ops.gemm_nt(col, fw[0], bias=fw[1], epi_act=ops.ACT_SILU)
+        h = h.view(B, OH, OW, -1)
+        feats, i = [], 2
+        for si, stage in enumerate(self.blocks):
+            for blk in stage:
+                wexp, b1, s2, b2, wproj, b3, wdw, wr, br, weT, be = fw[i:i + 11]
+                i += 11
+                Bh, H, W, Cin = h.shape
+                if wexp is not None:
+                    a1, _ = ops.gemm_nt(h.view(Bh * H * W, Cin), wexp, bias=b1, epi_act=ops.ACT_SILU)
+                    dw_in = a1.view(Bh, H, W, -1)
+                else:
+                    dw_in = h
+                y2, _ = ops.dwconv_fwd(dw_in, wdw, blk.k, blk.s)
+                _, OH2, OW2, Cm = y2.shape
+                M2 = Bh * OH2 * OW2
+                pool_part = ops.img_colsum(y2, None, s2, b2, ops.ACT_SILU)
+                _, _, gate = ops.se_gate_fwd(pool_part, OH2 * OW2, wr, br, weT, be)
+                out, _ = ops.gemm_nt(y2.view(M2, Cm), wproj, pscale=s2, pshift=b2, pro_act=ops.ACT_SILU, gate=gate,
+                                     rows_per_img=OH2 * OW2, bias=b3, add=h.view(M2, -1) if blk.has_skip else None)
+                h = out.view(Bh, OH2, OW2, -1)
+            if si in B3_FEATURE_STAGES:
+                feats.append(h)
+        return feats
+
     def forward_nhwc(self, x) -> List[torch.Tensor]:
+        if not self.training and not torch.is_grad_enabled() and x.is_cuda:
+            return self._infer_nhwc(x)
         cfg = _Cfg()
         cfg.dtype, cfg.bn = self.compute_dtype, ops.BNState(self.bn1)
         h = ops.StemFn.apply(x, self.conv_stem.weight, self.bn1.weight, self.bn1.bias, cfg)

@@ -245,3 +245,40 @@ def test_c5_finetune_path_fp32_inference():
         lm = mine(x.cuda(), "classification", "alzheimer")
     assert relerr(lm, lr) < 1e-4
     assert bool((lm.argmax(1).cpu() == lr.argmax(1)).all())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 4e-2)])
+def test_inference_path_with_folded_batchnorm(dtype, tol):
+    """Eval mode without autograd runs the trunk with BatchNorm folded into the 1x1 convolutions (weights scaled per
+    output channel, shift as GEMM bias, SiLU / residual in the GEMM epilogue); with autograd enabled the same module
+    runs the training-shaped kernels on the running statistics. Same five feature maps (fp32 within 3e-5, bf16 within
+    4e-2 of each other relative to each map's largest magnitude; fp32 also within 1e-4 of the CPU oracle), and the
+    folded weights follow in-place updates of parameters and buffers."""
+    ref = O.EfficientNetB3Features()
+    sd = seeded_state_dict(ref, 9)
+    ref.load_state_dict(sd)
+    ref.eval()
+    mine = EfficientNetB3Features(dtype)
+    mine.load_state_dict(sd)
+    mine.cuda().eval()
+    x = randn(55, 5, 3, 96, 128)
+    with torch.no_grad():
+        fast = [f.float().cpu() for f in mine(x.cuda())]
+        want = ref(x)
+    with torch.enable_grad():
+        slow = [f.detach().float().cpu() for f in mine(x.cuda())]
+    for a, b, r in zip(fast, slow, want):
+        assert a.shape == b.shape == r.shape
+        assert relerr(a, b) < tol
+        if dtype == torch.float32:
+            assert relerr(a, r) < 1e-4
+    # in-place changes must invalidate the folded copies
+    with torch.no_grad():
+        mine.blocks[1][0].bn1.running_var.mul_(1.7)
+        mine.blocks[6][1].conv_pwl.weight.mul_(0.5)
+        fast2 = [f.float().cpu() for f in mine(x.cuda())]
+    with torch.enable_grad():
+        slow2 = [f.detach().float().cpu() for f in mine(x.cuda())]
+    assert relerr(fast2[4], fast[4]) > 1e-2
+    for a, b in zip(fast2, slow2):
+        assert relerr(a, b) < tol
