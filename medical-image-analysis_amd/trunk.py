@@ -273,7 +273,11 @@ class EfficientNetB3Features(nn.Module):
 
     def forward_nhwc(self, x) -> List[torch.Tensor]:
         if not self.training and not torch.is_grad_enabled() and x.is_cuda:
-            return self._infer_nhwc(x)
+            bns = self.__dict__.get("_bn_list")
+            if bns is None:      # plain attribute (not a registered submodule list): the layers are fixed at construction
+                bns = self.__dict__["_bn_list"] = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+            if not any(m.training for m in bns):     # a layer left in train mode needs batch statistics
+                return self._infer_nhwc(x)
         cfg = _Cfg()
         cfg.dtype, cfg.bn = self.compute_dtype, ops.BNState(self.bn1)
         h = ops.StemFn.apply(x, self.conv_stem.weight, self.bn1.weight, self.bn1.bias, cfg)
