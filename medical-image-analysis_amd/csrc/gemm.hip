@@ -208,7 +208,9 @@ struct NtSlot {
 // once, one gate vector per tile where the tile lies in one image. The load INSTRUCTIONS, not their bytes, bound the
 // prologue there: 17 buffer loads per thread and stage in form 1, 7 in form 2 (24-wide projection of the 150x150 maps:
 // 192 -> 131 us). On the small maps form 2 measured slower (start-up round trip, two images in most tiles).
-template <typename T, int MT, int NT, int PRO, int DEPTH>
+// EPI: 1 general; 0 the launch has neither column statistics nor a bias (data gradients): their per-column registers
+// (3 per 16 columns) are not allocated, which takes the 128-row plain tiles from two to three workgroups per CU.
+template <typename T, int MT, int NT, int PRO, int DEPTH, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
     using M_ = Mma<T>;
     using V_ = Vec16<T>;
@@ -260,13 +262,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
     const int rstep = 256 >> cpr_log2;
     const float inv_rpi = 1.0f / (float)p.rows_per_img;
 
-    float st_sum[NT], st_sq[NT], bias_r[NT];   // bias of this lane's columns, read once (no loads in the epilogue)
+    constexpr int NE = EPI ? NT : 1;
+    float st_sum[NE], st_sq[NE], bias_r[NE];   // bias of this lane's columns, read once (no loads in the epilogue)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
+    for (int j = 0; j < NE; ++j) {
         st_sum[j] = st_sq[j] = 0.f;
         const int gn = n0 + j * 16 + (lane & 15);
-        bias_r[j] = (p.bias && gn < N) ? p.bias[gn] : 0.f;
+        bias_r[j] = (EPI && p.bias && gn < N) ? p.bias[gn] : 0.f;
     }
+    float* const stats = EPI ? p.stats : nullptr;
     const int tiles_m = (M + BM - 1) / BM;
 
     // row / rows_per_img without an integer division: float estimate, then one correction step either way
@@ -428,9 +432,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
         // ---------------------------------- epilogue (wave-local) ----------------------------------
         if (p.alias_cs) __syncthreads();  // every wave is done with As/Bs before the strips overwrite them
         const int lrow = (lane >> 4) * 4, lcol = lane & 15;
-        if (p.stats) {
+        if (EPI && stats) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+            for (int j = 0; j < NE; ++j)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
                 for (int j = 0; j < NT; ++j) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float v = acc[i][j][r] + bias_r[j];
+                        float v = EPI ? acc[i][j][r] + bias_r[EPI ? j : 0] : acc[i][j][r];
                         if (ACT == MIA_ACT_RELU) v = fmaxf(v, 0.f);
                         else if (ACT == MIA_ACT_SILU) v = siluf_(v);
                         Cw[(lrow + r) * LDC + j * 16 + lcol] = from_f32<T>(v);
@@ -510,12 +514,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
         while (tm < tiles_m) step(R0);
     }
 
-    if (p.stats) {
+    if (EPI && stats) {
         // lanes l, l+16, l+32, l+48 hold the same column: fold them, then fold the four waves through LDS
         __syncthreads();
         float* sred = reinterpret_cast<float*>(smem);  // [4][BN][2]
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        for (int j = 0; j < NE; ++j) {
             float s = st_sum[j], q = st_sq[j];
             s += __shfl_xor(s, 16, 64);
             q += __shfl_xor(q, 16, 64);
@@ -534,13 +538,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
                 s += sred[(w * BN + tid) * 2 + 0];
                 q += sred[(w * BN + tid) * 2 + 1];
             }
-            p.stats[((size_t)rowslot * 2 + 0) * N + n0 + tid] = s;
-            p.stats[((size_t)rowslot * 2 + 1) * N + n0 + tid] = q;
+            stats[((size_t)rowslot * 2 + 0) * N + n0 + tid] = s;
+            stats[((size_t)rowslot * 2 + 1) * N + n0 + tid] = q;
         }
     }
 }
 
-template <typename T, int MT, int NT, int PRO>
+template <typename T, int MT, int NT, int PRO, int EPI>
 static int launch_nt_(const GemmNTParams& p, int part_rows, hipStream_t stream);
 
 static int nt_stage_depth(int K, int full, int kstep) {
@@ -554,13 +558,14 @@ template <typename T, int MT, int NT>
 static int launch_nt(const GemmNTParams& p, int part_rows, hipStream_t stream) {
     if (p.pscale || p.gate) {
         // maps of 32x32 and more (the narrow tiles only: the wide ones never see such maps in this network)
-        if (NT <= 3 && p.rows_per_img >= 1024 && (2 * p.K * 4) <= 32 * 1024) return launch_nt_<T, MT, NT, (NT <= 3 ? 2 : 1)>(p, part_rows, stream);
-        return launch_nt_<T, MT, NT, 1>(p, part_rows, stream);
+        if (NT <= 3 && p.rows_per_img >= 1024 && (2 * p.K * 4) <= 32 * 1024) return launch_nt_<T, MT, NT, (NT <= 3 ? 2 : 1), 1>(p, part_rows, stream);
+        return launch_nt_<T, MT, NT, 1, 1>(p, part_rows, stream);
     }
-    return launch_nt_<T, MT, NT, 0>(p, part_rows, stream);
+    if (!p.stats && !p.bias) return launch_nt_<T, MT, NT, 0, 0>(p, part_rows, stream);
+    return launch_nt_<T, MT, NT, 0, 1>(p, part_rows, stream);
 }
 
-template <typename T, int MT, int NT, int PRO>
+template <typename T, int MT, int NT, int PRO, int EPI>
 static int launch_nt_(const GemmNTParams& p, int part_rows, hipStream_t stream) {
     using M_ = Mma<T>;
     constexpr int BM = 64 * MT, BN = 16 * NT;
@@ -585,7 +590,7 @@ static int launch_nt_(const GemmNTParams& p, int part_rows, hipStream_t stream) 
     if (PRO == 2) lds += (2 * p.K * 4 + 15) & ~15;
     dim3 grid((unsigned)(cdiv(q.row_slots, 8) * 8 * cdiv(p.N, BN)));
     // wide tiles and prologue variants are short of registers: one stage in flight; narrow plain ones stream: two
-    auto kern = gemm_nt_kernel<T, MT, NT, PRO, ((NT <= 6 && !PRO) ? 2 : 1)>;
+    auto kern = gemm_nt_kernel<T, MT, NT, PRO, ((NT <= 6 && !PRO) ? 2 : 1), EPI>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
