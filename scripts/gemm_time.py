@@ -13,6 +13,7 @@ from mia_amd import ops
 
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 FILT = sys.argv[2] if len(sys.argv) > 2 else ""
+TILE = int(os.environ.get("STATS_TILE", "64"))   # rows per BatchNorm partial row (the library default assumes 64-row tiles)
 
 
 def main():
@@ -28,7 +29,7 @@ def main():
         seen.add(key)
         a = torch.randn(M, K, device="cuda").bfloat16()
         b = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
-        kw = dict(stats_rows=ops.part_rows((M + 63) // 64) if stats else 0)
+        kw = dict(stats_rows=ops.part_rows((M + TILE - 1) // TILE) if stats else 0)
         if pro:
             kw.update(pscale=torch.rand(K, device="cuda") + 0.5, pshift=torch.randn(K, device="cuda") * 0.1,
                       pro_act=ops.ACT_SILU, gate=torch.rand(B, K, device="cuda"), rows_per_img=M // B)
