@@ -64,6 +64,19 @@ def test_gemm_nt_prologue_gate_stats(dtype, M, N, K, hw):
     assert relerr(s[1], (ref * ref).sum(0)) < tol(dtype, 1e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(50001, 816, 136), (40003, 1392, 232), (70001, 200, 64), (33001, 576, 96)])
+def test_gemm_nt_plain_tall(M, N, K):
+    """Data-gradient shaped launches (no statistics, no bias) tall enough for the 128-row tiles, with ragged last
+    row and column tiles, with and without the residual operand."""
+    a, b = rnd(M, K, seed=3, dtype=torch.bfloat16), rnd(N, K, seed=4, scale=K ** -0.5, dtype=torch.bfloat16)
+    d = rnd(M, N, seed=5, dtype=torch.bfloat16)
+    ref = a.float() @ b.float().t()
+    out, _ = ops.gemm_nt(a, b)
+    assert relerr(out.float(), ref) < tol(torch.bfloat16)
+    out, _ = ops.gemm_nt(a, b, add=d)
+    assert relerr(out.float(), ref + d.float()) < tol(torch.bfloat16)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_nt_bias_relu_add(dtype):
     M, N, K = 300, 512, 384
