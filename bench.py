@@ -7,7 +7,10 @@
 A step = forward + cross-entropy + backward (+ bucketed RCCL all-reduce) + AdamW on one synthetic batch that is
 already resident in HBM (128 MRI-shaped images per GPU: weak scaling, global batch 1024 at 8 GPUs). Prints ONE
 JSON line with the whole-job images/sec, the roofline of the dominant kernel family (HIP-event timed inside the
-timed region) and, at N=1, the CPU oracle timed on the host cores as a baseline.
+timed region), the library's kernel launches per step and, at N=1, the CPU oracle timed on the host cores as a
+baseline. --graph (one GPU only) replays the step as one HIP graph with the weight-gradient fork captured inside
+(graphs.GraphedTrainStep) instead of launching it eagerly; the default, and the headline, is the eager step that a
+train.py-style loop gets.
 """
 import argparse
 import json
@@ -82,6 +85,8 @@ def main():
     ap.add_argument("--linbn-min", type=int, default=0, help="A/B: smallest rows x expanded channels for that path")
     ap.add_argument("--no-fork", action="store_true", help="A/B switch: weight gradients on the main stream instead of the side stream")
     ap.add_argument("--kernel-table", action="store_true", help="also print a per-family timing table to stderr")
+    ap.add_argument("--graph", action="store_true",
+                    help="time HIP-graph replays of the step (single GPU; fork/join captured unless --no-fork)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -146,6 +151,19 @@ def main():
         opt.step()
         return loss
 
+    graphed = None
+    if args.graph:
+        if world > 1:
+            raise SystemExit("--graph is single-GPU: the gradient all-reduce is not captured")
+        from mia_amd.graphs import GraphedTrainStep
+        graphed = GraphedTrainStep(model, "classification", "synthetic", criterion, opt, xs[0], ys[0],
+                                   fork=not args.no_fork)
+
+        def step():     # noqa: F811  (the same step, replayed)
+            i = counter[0] % NBATCH
+            counter[0] += 1
+            return graphed(xs[i], ys[i], copy_out=False)
+
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -168,20 +186,38 @@ def main():
 
     barrier()
     ops.KernelTimer.start([dominant])
+    launches0 = mia_amd.lib().mia_launch_count()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
+    lib_launches = (mia_amd.lib().mia_launch_count() - launches0) / max(args.steps, 1)
     rec = ops.KernelTimer.stop().get(dominant, (0, 0.0, 0, 0))[:3]
+    if graphed is not None:
+        # a replay makes no library calls: the events and the launch count come from one eager step instead
+        ops.KernelTimer.start([dominant])
+        launches0 = mia_amd.lib().mia_launch_count()
+        opt.zero_grad(set_to_none=True)
+        criterion(model(xs[0], "classification", "synthetic"), ys[0]).backward()
+        lib_launches = mia_amd.lib().mia_launch_count() - launches0 + 1     # + the AdamW launch
+        rec = ops.KernelTimer.stop().get(dominant, (0, 0.0, 0, 0))[:3]
+        rec = (rec[0] * args.steps, rec[1] * args.steps, rec[2] * args.steps)
+        opt.zero_grad(set_to_none=True)
     # after the timed region: one more step with the weight-gradient stream off, every family event-timed. Each kernel
     # then has the chip to itself, so bytes / duration is the kernel's own rate (in the timed region the two streams
     # share the HBM and a kernel's duration depends on what runs beside it)
+    def eager_step():
+        opt.zero_grad(set_to_none=True)
+        reducer.zero_grad()
+        criterion(model(xs[0], "classification", "synthetic"), ys[0]).backward()
+        reducer.finish()
+        opt.step()
     side_was = ops.Side.enabled
     ops.Side.enabled = False
-    step()
+    eager_step()
     ops.KernelTimer.start(FAMILIES)
-    step()
+    eager_step()
     solo = ops.KernelTimer.stop()
     ops.Side.enabled = side_was
     if world > 1:
@@ -203,13 +239,18 @@ def main():
         ips = world * args.batch * args.steps / dt
         launches, ms, nbytes = rec
         achieved = (nbytes / (ms * 1e-3)) / 1e9 if ms > 0 else 0.0
+        # HBM bytes per launch from the counter passes on file: only when they were taken on THIS tree (the file
+        # carries the digest of the kernel sources it was measured on) and on this workload; otherwise null
         traffic = None
         try:
+            from mia_amd.build import kernel_tree_hash
             with open(TRAFFIC_FILE) as f:
-                fam = json.load(f)["families"].get(dominant)
-            if fam and args.batch == 128 and args.dtype == "bf16" and args.workload == "b3_cbam":
+                on_file = json.load(f)
+            fam = on_file["families"].get(dominant)
+            if (fam and on_file.get("tree") == kernel_tree_hash() and args.batch == 128 and args.dtype == "bf16"
+                    and args.workload == "b3_cbam"):
                 traffic = int(fam["hbm_bytes_per_launch"])
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, ImportError):
             pass
         out = {
             "metric": "train images/sec (whole node) EffNet-B3+CBAM 300x300 bf16",
@@ -218,9 +259,11 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"EfficientNet-B3 {'+ CBAM/MHA head' if use_attention else '(plain head)'}, 4 classes, "
                                    f"300x300, per-GPU batch {args.batch} (global {world * args.batch}), train step = "
-                                   f"fwd + CE + bwd + gradient all-reduce + AdamW; random-init weights, {NBATCH} synthetic "
-                                   "MRI-shaped batches resident in HBM, used in rotation",
+                                   f"fwd + CE + bwd + gradient all-reduce{' (no-op at 1 GPU)' if world == 1 else ''} + "
+                                   f"AdamW{', replayed as one HIP graph' if args.graph else ''}; random-init weights, "
+                                   f"{NBATCH} synthetic MRI-shaped batches resident in HBM, used in rotation",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                       "kernel_launches_per_step": round(lib_launches, 1),
                        "model_tflops_per_s": round(ips * TRAIN_GFLOP_PER_IMG[args.workload] / 1e3, 1)},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

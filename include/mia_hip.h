@@ -27,8 +27,12 @@ enum { MIA_ACT_NONE = 0, MIA_ACT_SILU = 1, MIA_ACT_RELU = 2 };
 
 const char* mia_last_error(void);
 int mia_version(void);
-/* 0 iff the current HIP device is gfx950. */
+/* 0 iff the current HIP device is gfx950. Also does the per-device set-up that must not happen for the first time
+ * inside a HIP graph capture (address lookup of the library's built-in device arrays). */
 int mia_check_device(void);
+/* Kernel launches this library has made in this process so far (all entry points, all devices). No counterpart in
+ * the reference: the benchmark reports launches per training step from the difference of two readings. */
+long long mia_launch_count(void);
 
 /* ---- pointwise (1x1) convolutions and linear layers: timm conv_pw / conv_pwl (src/model.py:283-288, :350),
  *      nn.Linear in the heads (src/model.py:125-130, :138, :141, :312, :315) --------------------------------
@@ -95,9 +99,10 @@ int mia_bn_finalize_fwd(const float* part, int P, int C, double count, const flo
 int mia_bn_finalize_bwd(const float* part, int P, int C, double count, const float* gamma, const float* mean,
                         const float* rstd, int training, float* dgamma, float* dbeta, float* ca, float* cb, float* cd,
                         float* dconv_bias, void* stream);
-/* g = (G*gate[b] + dpool[b]) * act'(Y*scale+shift) written over G (b = row / rows_per_img; gate, dpool optional);
- * part <- partials of sum(g), sum(g*(Y-mean)*rstd). */
-int mia_bn_act_bwd_reduce(int dtype, void* G, const void* Y, long long R, int C, const float* scale,
+/* g = (G*gate[b] + dpool[b]) * act'(Y*scale+shift) written to Out (b = row / rows_per_img; gate, dpool optional);
+ * part <- partials of sum(g), sum(g*(Y-mean)*rstd). Out may be G itself (in place) when the caller owns G; with
+ * neither activation nor gate nor dpool g equals G, nothing is written and Out may be null. */
+int mia_bn_act_bwd_reduce(int dtype, const void* G, void* Out, const void* Y, long long R, int C, const float* scale,
                           const float* shift, const float* mean, const float* rstd, int act, const float* gate,
                           const float* dpool, int rows_per_img, float* part, int part_rows, void* stream);
 /* G <- ca*[act'(Y*scale+shift) * (G*gate[b] + dpool[b])] + cb*Y + cd: activation, gate and BatchNorm backward
@@ -236,14 +241,19 @@ int mia_resize_normalize_u8(const uint8_t* src, int N, int h, int w, int ch, flo
 
 /* ---- zero-intensity slice filter. No counterpart in the reference (zi_remover.py:3-19 deletes Zone.Identifier
  *      files); specification: keep[z] = any(vol[z] != 0), idx = ascending kept indices, count[0] = their number.
- *      flags_ws: int32[n_slices] scratch. elem_bytes in {1,2,4}; is_float selects IEEE compare for 4-byte data. */
+ *      flags_ws: int32[n_slices] scratch, contents irrelevant on entry. elem_bytes in {1,2,4}; is_float selects the
+ *      IEEE compare for 4-byte data. Slices of up to 1 MiB take ONE launch (a workgroup per slice, the last one to
+ *      finish compacts); that path draws a ticket counter from a pool of 64 built into the library, so at most 64
+ *      calls may be in flight on one GPU at a time. */
 int mia_zero_slice_filter(const void* vol, int elem_bytes, int is_float, long long n_slices, long long slice_elems,
                           int* flags_ws, uint8_t* keep, int* idx, int* count, void* stream);
 /* The same filter for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc. No counterpart in the reference. The flag words live in a device array built into
  * the library (256 KiB per GPU, held until the process ends) instead of flags_ws; the entry point allocates nothing and
  * rejects n_slices > 65535. Calls on one GPU share that array: calls that overlap on the same GPU race. Results are
- * identical to mia_zero_slice_filter. */
+ * identical to mia_zero_slice_filter. The array's address is looked up once per device (hipGetSymbolAddress, under a
+ * host lock): make the first call on a device -- or call mia_check_device(), which does the lookup -- OUTSIDE any HIP
+ * graph capture. */
 int mia_zero_slice_filter_static(const void* vol, int elem_bytes, int is_float, long long n_slices,
                                  long long slice_elems, uint8_t* keep, int* idx, int* count, void* stream);
 /* out[k] = vol[idx[k]] for k < count[0] (count stays on the device: no host round trip). */

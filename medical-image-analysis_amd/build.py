@@ -13,6 +13,21 @@ LIB = os.path.join(HERE, "libmia_hip.so")
 SOURCES = ["runtime.hip", "gemm.hip", "dwconv.hip", "pointwise.hip", "head.hip", "preprocess.hip", "optim.hip", "seg.hip", "metrics.hip", "augment.hip"]
 
 
+def kernel_tree_hash() -> str:
+    """Digest of everything that decides which kernels a training step launches and what they move: the kernel
+    sources and the Python modules that sequence them. Measurements kept on file (HBM traffic per kernel from the
+    counter passes) carry the digest of the tree they were taken on, so a reader can tell whether they still apply."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files += [os.path.join(HERE, f) for f in ("ops.py", "trunk.py", "head_ops.py", "heads.py", "optim.py", "ddp.py")]
+    for path in files:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True

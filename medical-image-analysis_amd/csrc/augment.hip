@@ -141,7 +141,7 @@ extern "C" int mia_augment_normalize_u8(const uint8_t* src, int N, int H, int W,
     }
     long long blocks = ((long long)N * H * W + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(augment_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0,
+    MIA_LAUNCH(augment_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), src, N, H, W, params, dst, m[0], m[1], m[2], r[0], r[1], r[2]);
     MIA_CHECK_LAUNCH("mia_augment_normalize_u8");
     return 0;
@@ -152,7 +152,7 @@ extern "C" int mia_augment_mask_u8(const uint8_t* src, int N, int H, int W, cons
     MIA_CHECK_ARG(src && params && dst && N > 0 && H > 0 && W > 0, "mia_augment_mask_u8: bad arguments");
     long long blocks = ((long long)N * H * W + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(augment_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    MIA_LAUNCH(augment_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        src, N, H, W, params, dst);
     MIA_CHECK_LAUNCH("mia_augment_mask_u8");
     return 0;

@@ -7,6 +7,15 @@
 
 #define MIA_WAVE 64
 
+// Every kernel launch of the library goes through MIA_LAUNCH, which also counts it (mia_launch_count): the number of
+// launches per training step is a figure the benchmark reports, and the only place to count it without a profiler.
+extern unsigned long long g_mia_launches;
+#define MIA_LAUNCH(...)                    \
+    do {                                   \
+        ++g_mia_launches;                  \
+        hipLaunchKernelGGL(__VA_ARGS__);   \
+    } while (0)
+
 // ----------------------------------------------------------------------------------------------
 // error handling: every extern "C" entry returns 0 or a negative code and records a message.
 // ----------------------------------------------------------------------------------------------
@@ -239,7 +248,7 @@ static inline hipError_t mia_zero_words(void* p, long long n_words, hipStream_t 
     if (n_words <= 0) return hipSuccess;
     long long blocks = (n_words + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(mia_zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (unsigned*)p, n_words);
+    MIA_LAUNCH(mia_zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (unsigned*)p, n_words);
     return hipGetLastError();
 }
 

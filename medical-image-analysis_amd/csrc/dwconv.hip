@@ -911,7 +911,7 @@ static void launch_tile(const DwParams& p, int grid_x, hipStream_t s) {
     DwParams q = p;
     q.gx = grid_x; q.ncb = cdiv(p.C, p.CB);
     dim3 grid((unsigned)(q.gx * q.ncb));
-    hipLaunchKernelGGL((dwconv_tile_kernel<T, K, S, PH>), grid, dim3(256), lds, s, q);
+    MIA_LAUNCH((dwconv_tile_kernel<T, K, S, PH>), grid, dim3(256), lds, s, q);
 }
 
 template <typename T>
@@ -1002,8 +1002,8 @@ static int launch_mfma(DwParams& p, int K, int S, float* stats, int part_rows, h
     dim3 grid((unsigned)(p.gx * p.ncb));
 #define MIA_DWM(K_, S_) \
     do { \
-        if (p.CB == 64) hipLaunchKernelGGL((dwconv_mfma_kernel<K_, S_, 64>), grid, dim3(256), lds, s, p); \
-        else hipLaunchKernelGGL((dwconv_mfma_kernel<K_, S_, 32>), grid, dim3(256), lds, s, p); \
+        if (p.CB == 64) MIA_LAUNCH((dwconv_mfma_kernel<K_, S_, 64>), grid, dim3(256), lds, s, p); \
+        else MIA_LAUNCH((dwconv_mfma_kernel<K_, S_, 32>), grid, dim3(256), lds, s, p); \
     } while (0)
     if (K == 3 && S == 1) MIA_DWM(3, 1);
     else if (K == 3 && S == 2) MIA_DWM(3, 2);
@@ -1168,11 +1168,11 @@ extern "C" int mia_dwconv_bwd_data(int dtype, const void* dy, int B, int H, int 
         p.gx = gx; p.ncb = cdiv(C, p.CB);
         dim3 grid((unsigned)(p.gx * p.ncb));
         if (dtype == MIA_BF16) {
-            if (K == 3) hipLaunchKernelGGL((dwconv_bwd_data_s2_kernel<bf16_t, 3>), grid, dim3(256), lds, s, p);
-            else hipLaunchKernelGGL((dwconv_bwd_data_s2_kernel<bf16_t, 5>), grid, dim3(256), lds, s, p);
+            if (K == 3) MIA_LAUNCH((dwconv_bwd_data_s2_kernel<bf16_t, 3>), grid, dim3(256), lds, s, p);
+            else MIA_LAUNCH((dwconv_bwd_data_s2_kernel<bf16_t, 5>), grid, dim3(256), lds, s, p);
         } else {
-            if (K == 3) hipLaunchKernelGGL((dwconv_bwd_data_s2_kernel<float, 3>), grid, dim3(256), lds, s, p);
-            else hipLaunchKernelGGL((dwconv_bwd_data_s2_kernel<float, 5>), grid, dim3(256), lds, s, p);
+            if (K == 3) MIA_LAUNCH((dwconv_bwd_data_s2_kernel<float, 3>), grid, dim3(256), lds, s, p);
+            else MIA_LAUNCH((dwconv_bwd_data_s2_kernel<float, 5>), grid, dim3(256), lds, s, p);
         }
     }
     MIA_CHECK_LAUNCH("mia_dwconv_bwd_data");
@@ -1224,12 +1224,12 @@ extern "C" int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int
         const size_t lds = (size_t)npos16 * 4 + ((size_t)IHT * IWT + npos16) * DWG_CBP * 2;
         p.gx = (int)gx; p.ncb = ncb;
         dim3 grid((unsigned)(gx * ncb));
-        if (K == 3 && S == 1) hipLaunchKernelGGL((dwconv_bwdw_mfma_kernel<3, 1>), grid, dim3(256), lds, s, p, dy, ws);
-        else if (K == 3 && S == 2) hipLaunchKernelGGL((dwconv_bwdw_mfma_kernel<3, 2>), grid, dim3(256), lds, s, p, dy, ws);
-        else if (K == 5 && S == 1) hipLaunchKernelGGL((dwconv_bwdw_mfma_kernel<5, 1>), grid, dim3(256), lds, s, p, dy, ws);
-        else hipLaunchKernelGGL((dwconv_bwdw_mfma_kernel<5, 2>), grid, dim3(256), lds, s, p, dy, ws);
+        if (K == 3 && S == 1) MIA_LAUNCH((dwconv_bwdw_mfma_kernel<3, 1>), grid, dim3(256), lds, s, p, dy, ws);
+        else if (K == 3 && S == 2) MIA_LAUNCH((dwconv_bwdw_mfma_kernel<3, 2>), grid, dim3(256), lds, s, p, dy, ws);
+        else if (K == 5 && S == 1) MIA_LAUNCH((dwconv_bwdw_mfma_kernel<5, 1>), grid, dim3(256), lds, s, p, dy, ws);
+        else MIA_LAUNCH((dwconv_bwdw_mfma_kernel<5, 2>), grid, dim3(256), lds, s, p, dy, ws);
         const long long nout = (long long)C * K * K;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(nout, 32)), dim3(256), 0, s, ws, (int)gx, nout, dw);
+        MIA_LAUNCH(slab_reduce_kernel, dim3(cdiv(nout, 32)), dim3(256), 0, s, ws, (int)gx, nout, dw);
         MIA_CHECK_LAUNCH("mia_dwconv_bwd_weight");
         return 0;
     }
@@ -1248,7 +1248,7 @@ extern "C" int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int
     p.gx = (int)gx; p.ncb = ncb;
     dim3 grid((unsigned)(gx * ncb));
 #define MIA_DWW(T_, K_, S_, PH_) \
-    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T_, K_, S_>), grid, dim3(256), lds, s, p, dy, ws)
+    MIA_LAUNCH((dwconv_bwd_weight_kernel<T_, K_, S_>), grid, dim3(256), lds, s, p, dy, ws)
     if (dtype == MIA_BF16) {
         if (K == 3 && S == 1) MIA_DWW(bf16_t, 3, 1, 2);
         else if (K == 3 && S == 2) MIA_DWW(bf16_t, 3, 2, 1);
@@ -1262,7 +1262,7 @@ extern "C" int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int
     }
 #undef MIA_DWW
     const long long nout = (long long)C * K * K;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(nout, 32)), dim3(256), 0, s, ws, (int)gx, nout, dw);
+    MIA_LAUNCH(slab_reduce_kernel, dim3(cdiv(nout, 32)), dim3(256), 0, s, ws, (int)gx, nout, dw);
     MIA_CHECK_LAUNCH("mia_dwconv_bwd_weight");
     return 0;
 }

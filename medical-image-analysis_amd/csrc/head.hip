@@ -986,11 +986,11 @@ static void launch_attention_mfma_(bool fwd, const void* qkv, const float* P, co
     if (fwd) {
         auto k = attention_fwd_mfma_kernel<HD>;
         if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const bf16_t*)qkv, HW, C, heads, scale, pdrop, seed, seed_off, Pout, (bf16_t*)out);
+        MIA_LAUNCH(k, grid, dim3(256), lds, s, (const bf16_t*)qkv, HW, C, heads, scale, pdrop, seed, seed_off, Pout, (bf16_t*)out);
     } else {
         auto k = attention_bwd_mfma_kernel<HD>;
         if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const bf16_t*)qkv, P, (const bf16_t*)dout, (const bf16_t*)o, HW, C, heads, scale, pdrop, seed, seed_off, (bf16_t*)out);
+        MIA_LAUNCH(k, grid, dim3(256), lds, s, (const bf16_t*)qkv, P, (const bf16_t*)dout, (const bf16_t*)o, HW, C, heads, scale, pdrop, seed, seed_off, (bf16_t*)out);
     }
 }
 
@@ -1211,21 +1211,21 @@ extern "C" int mia_cbam_channel_fwd(int dtype, const void* x, int B, int HW, int
         float* pmax = psum + (size_t)B * splits * C;
         int* parg = reinterpret_cast<int*>(pmax + (size_t)B * splits * C);
         if (dtype == MIA_BF16)
-            hipLaunchKernelGGL(cbam_channel_pool_split_kernel<bf16_t>, dim3(B * splits), dim3(256), 0, MIA_STREAM,
+            MIA_LAUNCH(cbam_channel_pool_split_kernel<bf16_t>, dim3(B * splits), dim3(256), 0, MIA_STREAM,
                                (const bf16_t*)x, HW, C, splits, psum, pmax, parg);
         else
-            hipLaunchKernelGGL(cbam_channel_pool_split_kernel<float>, dim3(B * splits), dim3(256), 0, MIA_STREAM,
+            MIA_LAUNCH(cbam_channel_pool_split_kernel<float>, dim3(B * splits), dim3(256), 0, MIA_STREAM,
                                (const float*)x, HW, C, splits, psum, pmax, parg);
-        hipLaunchKernelGGL(cbam_channel_pool_combine_kernel, dim3(B, cdiv(C, 256)), dim3(256), 0, MIA_STREAM, psum, pmax,
+        MIA_LAUNCH(cbam_channel_pool_combine_kernel, dim3(B, cdiv(C, 256)), dim3(256), 0, MIA_STREAM, psum, pmax,
                            parg, HW, C, splits, avg, mx, amax);
     } else {
         dim3 g(B, cdiv(C, 256));
         if (dtype == MIA_BF16)
-            hipLaunchKernelGGL(cbam_channel_pool_kernel<bf16_t>, g, dim3(256), 0, MIA_STREAM, (const bf16_t*)x, HW, C, avg, mx, amax);
+            MIA_LAUNCH(cbam_channel_pool_kernel<bf16_t>, g, dim3(256), 0, MIA_STREAM, (const bf16_t*)x, HW, C, avg, mx, amax);
         else
-            hipLaunchKernelGGL(cbam_channel_pool_kernel<float>, g, dim3(256), 0, MIA_STREAM, (const float*)x, HW, C, avg, mx, amax);
+            MIA_LAUNCH(cbam_channel_pool_kernel<float>, g, dim3(256), 0, MIA_STREAM, (const float*)x, HW, C, avg, mx, amax);
     }
-    hipLaunchKernelGGL(cbam_channel_mlp_kernel, dim3(B), dim3(256), (size_t)(2 * C + HID) * 4, MIA_STREAM, avg, mx, C, HID,
+    MIA_LAUNCH(cbam_channel_mlp_kernel, dim3(B), dim3(256), (size_t)(2 * C + HID) * 4, MIA_STREAM, avg, mx, C, HID,
                        W1, b1, W2, b2, ha, hm, cscale);
     MIA_CHECK_LAUNCH("mia_cbam_channel_fwd");
     return 0;
@@ -1239,12 +1239,12 @@ extern "C" int mia_cbam_spatial_fwd(int dtype, const void* x, const float* cscal
     MIA_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && part_rows > 0 && part_rows <= 65535, "mia_cbam_spatial_fwd: bad shape");
     const long long npix = (long long)B * H * W;
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(cbam_spatial_pool_kernel<bf16_t>, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, MIA_STREAM,
+        MIA_LAUNCH(cbam_spatial_pool_kernel<bf16_t>, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, MIA_STREAM,
                            (const bf16_t*)x, cscale, B, H * W, C, comp, cmax);
     else
-        hipLaunchKernelGGL(cbam_spatial_pool_kernel<float>, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, MIA_STREAM,
+        MIA_LAUNCH(cbam_spatial_pool_kernel<float>, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, MIA_STREAM,
                            (const float*)x, cscale, B, H * W, C, comp, cmax);
-    hipLaunchKernelGGL(cbam_spatial_conv_kernel, dim3(part_rows), dim3(256), 0, MIA_STREAM, comp, B, H, W, w7, pre, part);
+    MIA_LAUNCH(cbam_spatial_conv_kernel, dim3(part_rows), dim3(256), 0, MIA_STREAM, comp, B, H, W, w7, pre, part);
     MIA_CHECK_LAUNCH("mia_cbam_spatial_fwd");
     return 0;
 }
@@ -1255,10 +1255,10 @@ extern "C" int mia_cbam_apply(int dtype, const void* x, const float* cscale, con
     MIA_CHECK_ARG(x && cscale && pre && bnst && out && sgate && C % 4 == 0, "mia_cbam_apply: bad arguments");
     const unsigned g = grid1d((long long)B * HW * C / 4);
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(cbam_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, MIA_STREAM, (const bf16_t*)x, cscale, pre, bnst,
+        MIA_LAUNCH(cbam_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, MIA_STREAM, (const bf16_t*)x, cscale, pre, bnst,
                            B, HW, C, (bf16_t*)out, sgate);
     else
-        hipLaunchKernelGGL(cbam_apply_kernel<float>, dim3(g), dim3(256), 0, MIA_STREAM, (const float*)x, cscale, pre, bnst, B,
+        MIA_LAUNCH(cbam_apply_kernel<float>, dim3(g), dim3(256), 0, MIA_STREAM, (const float*)x, cscale, pre, bnst, B,
                            HW, C, (float*)out, sgate);
     MIA_CHECK_LAUNCH("mia_cbam_apply");
     return 0;
@@ -1294,50 +1294,50 @@ extern "C" int mia_cbam_bwd(int dtype, const void* dx2, const void* x, int B, in
     hipStream_t s = MIA_STREAM;
     const unsigned gp = (unsigned)((npix + 3) / 4);
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(cbam_bwd_dsgate_kernel<bf16_t>, dim3(gp), dim3(256), 0, s, (const bf16_t*)dx2, (const bf16_t*)x,
+        MIA_LAUNCH(cbam_bwd_dsgate_kernel<bf16_t>, dim3(gp), dim3(256), 0, s, (const bf16_t*)dx2, (const bf16_t*)x,
                            cscale, B, HW, C, dsg);
     else
-        hipLaunchKernelGGL(cbam_bwd_dsgate_kernel<float>, dim3(gp), dim3(256), 0, s, (const float*)dx2, (const float*)x,
+        MIA_LAUNCH(cbam_bwd_dsgate_kernel<float>, dim3(gp), dim3(256), 0, s, (const float*)dx2, (const float*)x,
                            cscale, B, HW, C, dsg);
     if (bn_parts > 0) {
-        hipLaunchKernelGGL(cbam_bwd_spatial_bn_part_kernel, dim3(bn_parts), dim3(256), 0, s, dsg, sgate, pre, bnst, npix,
+        MIA_LAUNCH(cbam_bwd_spatial_bn_part_kernel, dim3(bn_parts), dim3(256), 0, s, dsg, sgate, pre, bnst, npix,
                            bn_part);
-        hipLaunchKernelGGL(cbam_bwd_spatial_bn_apply_kernel, dim3(grid1d(npix, 1024)), dim3(256), 0, s, dsg, sgate, pre,
+        MIA_LAUNCH(cbam_bwd_spatial_bn_apply_kernel, dim3(grid1d(npix, 1024)), dim3(256), 0, s, dsg, sgate, pre,
                            bnst, bn_gamma, bn_training, npix, bn_part, bn_parts, dpre, dbn_gamma, dbn_beta);
     } else {
-        hipLaunchKernelGGL(cbam_bwd_spatial_bn_kernel, dim3(1), dim3(1024), 0, s, dsg, sgate, pre, bnst, bn_gamma,
+        MIA_LAUNCH(cbam_bwd_spatial_bn_kernel, dim3(1), dim3(1024), 0, s, dsg, sgate, pre, bnst, bn_gamma,
                            bn_training, npix, dpre, dbn_gamma, dbn_beta);
     }
-    hipLaunchKernelGGL(cbam_bwd_conv_weight_kernel, dim3(98, chunks), dim3(256), 0, s, dpre, comp, B, H, W,
+    MIA_LAUNCH(cbam_bwd_conv_weight_kernel, dim3(98, chunks), dim3(256), 0, s, dpre, comp, B, H, W,
                        chunks > 1 ? cw_part : dw7);
-    if (chunks > 1) hipLaunchKernelGGL(cbam_bwd_conv_weight_fold_kernel, dim3(1), dim3(128), 0, s, cw_part, chunks, dw7);
-    hipLaunchKernelGGL(cbam_bwd_conv_data_kernel, dim3(grid1d(npix)), dim3(256), 0, s, dpre, B, H, W, w7, dcomp);
+    if (chunks > 1) MIA_LAUNCH(cbam_bwd_conv_weight_fold_kernel, dim3(1), dim3(128), 0, s, cw_part, chunks, dw7);
+    MIA_LAUNCH(cbam_bwd_conv_data_kernel, dim3(grid1d(npix)), dim3(256), 0, s, dpre, B, H, W, w7, dcomp);
     if (splits > 1) {
         if (dtype == MIA_BF16)
-            hipLaunchKernelGGL(cbam_bwd_dcs_split_kernel<bf16_t>, dim3(B * splits), dim3(256), 0, s, (const bf16_t*)dx2,
+            MIA_LAUNCH(cbam_bwd_dcs_split_kernel<bf16_t>, dim3(B * splits), dim3(256), 0, s, (const bf16_t*)dx2,
                                (const bf16_t*)x, sgate, dcomp, cmax, HW, C, splits, dcs_part);
         else
-            hipLaunchKernelGGL(cbam_bwd_dcs_split_kernel<float>, dim3(B * splits), dim3(256), 0, s, (const float*)dx2,
+            MIA_LAUNCH(cbam_bwd_dcs_split_kernel<float>, dim3(B * splits), dim3(256), 0, s, (const float*)dx2,
                                (const float*)x, sgate, dcomp, cmax, HW, C, splits, dcs_part);
     } else {
         dim3 gc(B, cdiv(C, 256));
         if (dtype == MIA_BF16)
-            hipLaunchKernelGGL(cbam_bwd_dcs_kernel<bf16_t>, gc, dim3(256), 0, s, (const bf16_t*)dx2, (const bf16_t*)x, sgate,
+            MIA_LAUNCH(cbam_bwd_dcs_kernel<bf16_t>, gc, dim3(256), 0, s, (const bf16_t*)dx2, (const bf16_t*)x, sgate,
                                dcomp, cmax, HW, C, dcs);
         else
-            hipLaunchKernelGGL(cbam_bwd_dcs_kernel<float>, gc, dim3(256), 0, s, (const float*)dx2, (const float*)x, sgate,
+            MIA_LAUNCH(cbam_bwd_dcs_kernel<float>, gc, dim3(256), 0, s, (const float*)dx2, (const float*)x, sgate,
                                dcomp, cmax, HW, C, dcs);
     }
-    hipLaunchKernelGGL(cbam_bwd_mlp_kernel, dim3(B), dim3(256), (size_t)(C + 2 * HID) * 4, s, splits > 1 ? dcs_part : dcs,
+    MIA_LAUNCH(cbam_bwd_mlp_kernel, dim3(B), dim3(256), (size_t)(C + 2 * HID) * 4, s, splits > 1 ? dcs_part : dcs,
                        splits > 1 ? splits : 1, cscale, ha, hm, C, HID, W1, W2, datt, dpa, dpm, davg, dmax);
-    hipLaunchKernelGGL(cbam_bwd_mlp_param_kernel, dim3(cdiv((long long)C * HID, 256)), dim3(256), 0, s, B, C, HID, datt, dpa,
+    MIA_LAUNCH(cbam_bwd_mlp_param_kernel, dim3(cdiv((long long)C * HID, 256)), dim3(256), 0, s, B, C, HID, datt, dpa,
                        dpm, ha, hm, avg, mx, dW1, db1, dW2, db2);
     const unsigned ge = grid1d((long long)B * HW * C);
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(cbam_bwd_dx_kernel<bf16_t>, dim3(ge), dim3(256), 0, s, (const bf16_t*)dx2, sgate, dcomp, cmax,
+        MIA_LAUNCH(cbam_bwd_dx_kernel<bf16_t>, dim3(ge), dim3(256), 0, s, (const bf16_t*)dx2, sgate, dcomp, cmax,
                            cscale, davg, dmax, amax, B, HW, C, (bf16_t*)dx);
     else
-        hipLaunchKernelGGL(cbam_bwd_dx_kernel<float>, dim3(ge), dim3(256), 0, s, (const float*)dx2, sgate, dcomp, cmax, cscale,
+        MIA_LAUNCH(cbam_bwd_dx_kernel<float>, dim3(ge), dim3(256), 0, s, (const float*)dx2, sgate, dcomp, cmax, cscale,
                            davg, dmax, amax, B, HW, C, (float*)dx);
     MIA_CHECK_LAUNCH("mia_cbam_bwd");
     return 0;
@@ -1365,11 +1365,11 @@ static int launch_attention(bool fwd, const void* qkv, const float* P, const voi
         if (fwd) {                                                                                                    \
             auto k = attention_fwd_kernel<T, HD_>;                                                                    \
             if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const T*)qkv, HW, C, heads, scale, pdrop, seed, seed_off, Pout, (T*)out); \
+            MIA_LAUNCH(k, grid, dim3(256), lds, s, (const T*)qkv, HW, C, heads, scale, pdrop, seed, seed_off, Pout, (T*)out); \
         } else {                                                                                                      \
             auto k = attention_bwd_kernel<T, HD_>;                                                                    \
             if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const T*)qkv, P, (const T*)dout, (const T*)o, HW, C, heads, scale, pdrop, seed, seed_off, (T*)out); \
+            MIA_LAUNCH(k, grid, dim3(256), lds, s, (const T*)qkv, P, (const T*)dout, (const T*)o, HW, C, heads, scale, pdrop, seed, seed_off, (T*)out); \
         }                                                                                                             \
     } while (0)
     if (HD == 48) MIA_ATT(48);
@@ -1428,7 +1428,7 @@ extern "C" int mia_pool_ln_dropout_fwd(const float* in_part, int B, int S, int H
                                        float* xhat, float* rstd, void* stream) {
     MIA_CHECK_ARG(in_part && out && xhat && rstd && B > 0 && S > 0 && HW > 0 && C > 0, "mia_pool_ln_dropout_fwd: bad arguments");
     MIA_CHECK_ARG(!(gamma == nullptr) == !(beta == nullptr), "mia_pool_ln_dropout_fwd: gamma/beta come together");
-    hipLaunchKernelGGL(pool_ln_dropout_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, MIA_STREAM, in_part, B, S, C,
+    MIA_LAUNCH(pool_ln_dropout_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, MIA_STREAM, in_part, B, S, C,
                        1.0f / (float)HW, gamma, beta, eps, pdrop, seed, seed_offset, out, xhat, rstd);
     MIA_CHECK_LAUNCH("mia_pool_ln_dropout_fwd");
     return 0;
@@ -1440,7 +1440,7 @@ extern "C" int mia_pool_ln_dropout_bwd(const float* dout, int B, int C, const fl
                                        float* dgamma_rows, float* dbeta_rows, void* stream) {
     MIA_CHECK_ARG(dout && dpooled && B > 0 && C > 0, "mia_pool_ln_dropout_bwd: bad arguments");
     MIA_CHECK_ARG(!gamma || (xhat && rstd && dgamma_rows && dbeta_rows), "mia_pool_ln_dropout_bwd: LayerNorm needs its state");
-    hipLaunchKernelGGL(pool_ln_dropout_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, MIA_STREAM, dout, B, C, gamma, xhat, rstd,
+    MIA_LAUNCH(pool_ln_dropout_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, MIA_STREAM, dout, B, C, gamma, xhat, rstd,
                        pdrop, seed, seed_offset, dpooled, dgamma_rows, dbeta_rows);
     MIA_CHECK_LAUNCH("mia_pool_ln_dropout_bwd");
     return 0;
@@ -1451,10 +1451,10 @@ extern "C" int mia_broadcast_rows(int dtype, const float* v, int B, int HW, int 
     MIA_CHECK_ARG(v && out && B > 0 && HW > 0 && C > 0 && C % 4 == 0, "mia_broadcast_rows: bad arguments");
     const unsigned g = grid1d((long long)B * HW * C / 4);
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(broadcast_rows_kernel<bf16_t>, dim3(g), dim3(256), 0, MIA_STREAM, v, B, HW, C, mult,
+        MIA_LAUNCH(broadcast_rows_kernel<bf16_t>, dim3(g), dim3(256), 0, MIA_STREAM, v, B, HW, C, mult,
                            (const bf16_t*)res, (bf16_t*)out);
     else
-        hipLaunchKernelGGL(broadcast_rows_kernel<float>, dim3(g), dim3(256), 0, MIA_STREAM, v, B, HW, C, mult,
+        MIA_LAUNCH(broadcast_rows_kernel<float>, dim3(g), dim3(256), 0, MIA_STREAM, v, B, HW, C, mult,
                            (const float*)res, (float*)out);
     MIA_CHECK_LAUNCH("mia_broadcast_rows");
     return 0;
@@ -1464,7 +1464,7 @@ extern "C" int mia_dropout_f32(float* x, const float* relu_ref, long long n, flo
                                const unsigned long long* seed_offset,
                                void* stream) {
     MIA_CHECK_ARG(x && n > 0, "mia_dropout_f32: bad arguments");
-    hipLaunchKernelGGL(dropout_f32_kernel, dim3(grid1d(n)), dim3(256), 0, MIA_STREAM, x, relu_ref, n, pdrop, seed, seed_offset);
+    MIA_LAUNCH(dropout_f32_kernel, dim3(grid1d(n)), dim3(256), 0, MIA_STREAM, x, relu_ref, n, pdrop, seed, seed_offset);
     MIA_CHECK_LAUNCH("mia_dropout_f32");
     return 0;
 }
@@ -1480,11 +1480,11 @@ extern "C" int mia_colsum(int dtype, const void* x, long long R, int C, int ld, 
     float* part = chunks == 1 ? out : ws;
     dim3 grid(cdiv(C, 64), (unsigned)chunks);
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, MIA_STREAM, (const bf16_t*)x, R, C, ld, part);
+        MIA_LAUNCH(colsum_kernel<bf16_t>, grid, dim3(256), 0, MIA_STREAM, (const bf16_t*)x, R, C, ld, part);
     else
-        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, MIA_STREAM, (const float*)x, R, C, ld, part);
+        MIA_LAUNCH(colsum_kernel<float>, grid, dim3(256), 0, MIA_STREAM, (const float*)x, R, C, ld, part);
     if (chunks > 1)
-        hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, MIA_STREAM, part, (int)chunks, C, out);
+        MIA_LAUNCH(colsum_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, MIA_STREAM, part, (int)chunks, C, out);
     MIA_CHECK_LAUNCH("mia_colsum");
     return 0;
 }
@@ -1492,7 +1492,7 @@ extern "C" int mia_colsum(int dtype, const void* x, long long R, int C, int ld, 
 extern "C" int mia_softmax_ce(const float* logits, int ld, const long long* labels, int B, int n, float* loss,
                               float* dlogits, int ldd, void* stream) {
     MIA_CHECK_ARG(logits && labels && loss && dlogits && B > 0 && n > 0 && ld >= n && ldd >= n, "mia_softmax_ce: bad arguments");
-    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, MIA_STREAM, logits, labels, B, n, ld, loss, dlogits, ldd);
+    MIA_LAUNCH(softmax_ce_kernel, dim3(1), dim3(256), 0, MIA_STREAM, logits, labels, B, n, ld, loss, dlogits, ldd);
     MIA_CHECK_LAUNCH("mia_softmax_ce");
     return 0;
 }

@@ -43,7 +43,7 @@ extern "C" int mia_confusion_update(const float* logits, long long stride_image,
     long long blocks = (total + 256 * 8 - 1) / (256 * 8);
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits,
+    MIA_LAUNCH(confusion_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits,
                        stride_image, stride_class, stride_pos, target, total, positions, n, conf, loss, loss_acc);
     MIA_CHECK_LAUNCH("mia_confusion_update");
     return 0;

@@ -124,7 +124,7 @@ extern "C" int mia_adamw_step(int n_tensors, const void* const* params, const vo
         }
         if (c.count == 0) continue;
         c.first_block[c.count] = blocks;
-        hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, s, c, dev_hyper);
+        MIA_LAUNCH(adamw_kernel, dim3(blocks), dim3(256), 0, s, c, dev_hyper);
         MIA_CHECK_LAUNCH("mia_adamw_step");
     }
     return 0;
@@ -149,7 +149,7 @@ extern "C" int mia_set_words(void* dst, int n, const unsigned* host_words, void*
     MIA_CHECK_ARG(dst && host_words, "mia_set_words: null pointer");
     WordPack v;
     for (int i = 0; i < MIA_SET_WORDS_MAX; ++i) v.w[i] = i < n ? host_words[i] : 0u;
-    hipLaunchKernelGGL(set_words_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), (unsigned*)dst, n,
+    MIA_LAUNCH(set_words_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), (unsigned*)dst, n,
                        v);
     MIA_CHECK_LAUNCH("mia_set_words");
     return 0;

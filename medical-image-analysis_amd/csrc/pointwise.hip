@@ -114,7 +114,7 @@ extern "C" int mia_bn_finalize_fwd(const float* part, int P, int C, double count
     MIA_CHECK_ARG(C > 0 && scale && shift && mean && rstd, "mia_bn_finalize_fwd: bad arguments");
     MIA_CHECK_ARG(!training || (part && P > 0 && count > 0), "mia_bn_finalize_fwd: training needs partials");
     MIA_CHECK_ARG(training || (running_mean && running_var), "mia_bn_finalize_fwd: eval needs running stats");
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    MIA_LAUNCH(bn_finalize_fwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        part, P, C, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
                        training, conv_bias, scale, shift, mean, rstd);
     MIA_CHECK_LAUNCH("mia_bn_finalize_fwd");
@@ -163,18 +163,18 @@ extern "C" int mia_bn_finalize_bwd(const float* part, int P, int C, double count
                                    float* ca, float* cb, float* cd, float* dconv_bias, void* stream) {
     MIA_CHECK_ARG(part && P > 0 && C > 0 && count > 0 && mean && rstd && ca && cb && cd,
                   "mia_bn_finalize_bwd: bad arguments");
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    MIA_LAUNCH(bn_finalize_bwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        part, P, C, count, gamma, mean, rstd, training, dgamma, dbeta, ca, cb, cd, dconv_bias);
     MIA_CHECK_LAUNCH("mia_bn_finalize_bwd");
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward reduce: g = (G * gate[b] + dpool[b]) * act'(y*scale+shift), written over G;
+// backward reduce: g = (G * gate[b] + dpool[b]) * act'(y*scale+shift), written to Out (which may be G itself);
 // partials sum(g), sum(g * (y-mean)*rstd) per channel
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(T* G, const T* Y, long long R, int C, int CB,
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* G, T* Out, const T* Y, long long R, int C, int CB,
                                                                 const float* scale, const float* shift,
                                                                 const float* mean, const float* rstd, int act,
                                                                 const float* gate, const float* dpool,
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(T* G, const T* Y
             s2.lo += g.lo; s2.hi += g.hi;
             q2.lo += g.lo * ((y.lo - mu.lo) * rs.lo);
             q2.hi += g.hi * ((y.hi - mu.hi) * rs.hi);
-            if (writes) store22<T>(G + (size_t)r * C + m.c, g);
+            if (writes) store22<T>(Out + (size_t)r * C + m.c, g);
         };
         long long r = (long long)blockIdx.x * m.npt + m.pt;
         // 4 rows per iteration: 8 independent vector loads in flight per lane
@@ -229,12 +229,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(T* G, const T* Y
     block_colsum2(red, m, tid, s, q, part + ((size_t)blockIdx.x * 2 + 0) * C, part + ((size_t)blockIdx.x * 2 + 1) * C);
 }
 
-extern "C" int mia_bn_act_bwd_reduce(int dtype, void* G, const void* Y, long long R, int C, const float* scale,
+extern "C" int mia_bn_act_bwd_reduce(int dtype, const void* G, void* Out, const void* Y, long long R, int C, const float* scale,
                                      const float* shift, const float* mean, const float* rstd, int act,
                                      const float* gate, const float* dpool, int rows_per_img, float* part,
                                      int part_rows, void* stream) {
     MIA_CHECK_ARG(G && Y && R > 0 && C > 0 && C % 4 == 0 && scale && shift && mean && rstd && part,
                   "mia_bn_act_bwd_reduce: bad arguments");
+    MIA_CHECK_ARG(Out || !(act != MIA_ACT_NONE || gate || dpool),
+                  "mia_bn_act_bwd_reduce: an activation, gate or dpool changes the gradient: Out must be given");
     MIA_CHECK_ARG(part_rows > 0 && part_rows <= 65535, "mia_bn_act_bwd_reduce: bad part_rows");
     MIA_CHECK_ARG(!(gate || dpool) || rows_per_img > 0, "mia_bn_act_bwd_reduce: gate/dpool need rows_per_img");
     MIA_CHECK_ARG(R < (1LL << 32), "mia_bn_act_bwd_reduce: too many rows");
@@ -244,10 +246,10 @@ extern "C" int mia_bn_act_bwd_reduce(int dtype, void* G, const void* Y, long lon
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (rows_per_img <= 0) rows_per_img = 1;
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)G, (const bf16_t*)Y, R, C,
+        MIA_LAUNCH(bn_act_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)G, (bf16_t*)Out, (const bf16_t*)Y, R, C,
                            CB, scale, shift, mean, rstd, act, gate, dpool, rows_per_img, part);
     else
-        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, (float*)G, (const float*)Y, R, C, CB,
+        MIA_LAUNCH(bn_act_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)G, (float*)Out, (const float*)Y, R, C, CB,
                            scale, shift, mean, rstd, act, gate, dpool, rows_per_img, part);
     MIA_CHECK_LAUNCH("mia_bn_act_bwd_reduce");
     return 0;
@@ -380,19 +382,19 @@ extern "C" int mia_affine2(int dtype, const void* X, const void* Y, const void* 
             if (unit <= wblocks) { wblocks = wblocks / unit * unit; fixed_c = 1; }
         }
         if (dtype == MIA_BF16)
-            hipLaunchKernelGGL(affine2_wide_kernel<bf16_t>, dim3((unsigned)wblocks), dim3(256), 0, s, (const bf16_t*)X,
+            MIA_LAUNCH(affine2_wide_kernel<bf16_t>, dim3((unsigned)wblocks), dim3(256), 0, s, (const bf16_t*)X,
                                (const bf16_t*)Y, (const bf16_t*)Res, (bf16_t*)Out, (unsigned)nvec8, C, a, b, d, act, fixed_c);
         else
-            hipLaunchKernelGGL(affine2_wide_kernel<float>, dim3((unsigned)wblocks), dim3(256), 0, s, (const float*)X,
+            MIA_LAUNCH(affine2_wide_kernel<float>, dim3((unsigned)wblocks), dim3(256), 0, s, (const float*)X,
                                (const float*)Y, (const float*)Res, (float*)Out, (unsigned)nvec8, C, a, b, d, act, fixed_c);
         MIA_CHECK_LAUNCH("mia_affine2");
         return 0;
     }
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(affine2_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)X,
+        MIA_LAUNCH(affine2_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)X,
                            (const bf16_t*)Y, (const bf16_t*)Res, (bf16_t*)Out, nvec, C, a, b, d, act);
     else
-        hipLaunchKernelGGL(affine2_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)X,
+        MIA_LAUNCH(affine2_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)X,
                            (const float*)Y, (const float*)Res, (float*)Out, nvec, C, a, b, d, act);
     MIA_CHECK_LAUNCH("mia_affine2");
     return 0;
@@ -456,10 +458,10 @@ extern "C" int mia_img_colsum(int dtype, const void* Y, const void* Wt, int B, i
     dim3 grid(B * splits, ncb);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(img_colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)Y, (const bf16_t*)Wt, HW, C,
+        MIA_LAUNCH(img_colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)Y, (const bf16_t*)Wt, HW, C,
                            CB, splits, scale, shift, act, out);
     else
-        hipLaunchKernelGGL(img_colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)Y, (const float*)Wt, HW, C, CB,
+        MIA_LAUNCH(img_colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)Y, (const float*)Wt, HW, C, CB,
                            splits, scale, shift, act, out);
     MIA_CHECK_LAUNCH("mia_img_colsum");
     return 0;
@@ -539,10 +541,10 @@ extern "C" int mia_se_bwd_sums(int dtype, const void* Y, const void* dZ, int B, 
     dim3 grid(B * splits, ncb);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(se_bwd_sums_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)Y, (const bf16_t*)dZ, B, HW,
+        MIA_LAUNCH(se_bwd_sums_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)Y, (const bf16_t*)dZ, B, HW,
                            C, CB, splits, scale, shift, mean, rstd, out);
     else
-        hipLaunchKernelGGL(se_bwd_sums_kernel<float>, grid, dim3(256), 0, s, (const float*)Y, (const float*)dZ, B, HW, C,
+        MIA_LAUNCH(se_bwd_sums_kernel<float>, grid, dim3(256), 0, s, (const float*)Y, (const float*)dZ, B, HW, C,
                            CB, splits, scale, shift, mean, rstd, out);
     MIA_CHECK_LAUNCH("mia_se_bwd_sums");
     return 0;
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(256) void se_bn_combine_kernel(const float* sums, i
 extern "C" int mia_se_bn_combine(const float* sums, int B, int splits, int C, const float* gate, const float* dpool,
                                  float* part, void* stream) {
     MIA_CHECK_ARG(sums && gate && dpool && part && B > 0 && splits > 0 && C > 0, "mia_se_bn_combine: bad arguments");
-    hipLaunchKernelGGL(se_bn_combine_kernel, dim3(cdiv((long long)B * C, 256)), dim3(256), 0,
+    MIA_LAUNCH(se_bn_combine_kernel, dim3(cdiv((long long)B * C, 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), sums, B, splits, C, gate, dpool, part);
     MIA_CHECK_LAUNCH("mia_se_bn_combine");
     return 0;
@@ -703,7 +705,7 @@ extern "C" int mia_bn_act_bwd_apply(int dtype, void* G, const void* Y, long long
     const unsigned vpi = (unsigned)((long long)(rows_per_img > 0 ? rows_per_img : 1) * C / W);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define MIA_APPLY(T_, W_)                                                                                          \
-    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T_, W_>), dim3((unsigned)blocks), dim3(256), 0, s, (T_*)G, (const T_*)Y, \
+    MIA_LAUNCH((bn_act_bwd_apply_kernel<T_, W_>), dim3((unsigned)blocks), dim3(256), 0, s, (T_*)G, (const T_*)Y, \
                        (unsigned)nvec, C, scale, shift, act, gate, dpool, vpi, ca, cb, cd, fixed_c)
     if (dtype == MIA_BF16) { if (wide) MIA_APPLY(bf16_t, 8); else MIA_APPLY(bf16_t, 4); }
     else { if (wide) MIA_APPLY(float, 8); else MIA_APPLY(float, 4); }
@@ -864,16 +866,16 @@ extern "C" int mia_se_gate_fwd(const float* pool_part, int B, int splits, int HW
                   "mia_se_gate_fwd: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (se_wide(C, RD)) {
-        hipLaunchKernelGGL(se_prep_kernel, dim3(cdiv((long long)B * C, 256)), dim3(256), 0, s, pool_part, splits,
+        MIA_LAUNCH(se_prep_kernel, dim3(cdiv((long long)B * C, 256)), dim3(256), 0, s, pool_part, splits,
                            1.0f / (float)HW, C, B * C, (const float*)nullptr, 0, pooled);
         const int waves = cdiv(RD, SE_JT) * cdiv(B, SE_IB);
-        hipLaunchKernelGGL(se_reduce_c_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, s, Wr, pooled, B, C, RD, br,
+        MIA_LAUNCH(se_reduce_c_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, s, Wr, pooled, B, C, RD, br,
                            (const float*)nullptr, 0, hpre);
-        hipLaunchKernelGGL(se_expand_kernel, dim3(cdiv(C, 256), cdiv(B, SE_IB)), dim3(256), (size_t)RD * SE_IB * 4, s,
+        MIA_LAUNCH(se_expand_kernel, dim3(cdiv(C, 256), cdiv(B, SE_IB)), dim3(256), (size_t)RD * SE_IB * 4, s,
                            WeT, hpre, B, C, RD, be, 1.f, 0, gate);
     } else {
         const size_t lds = (size_t)(C + RD) * 4;
-        hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(256), lds, s, pool_part, splits, 1.0f / (float)HW, C, RD,
+        MIA_LAUNCH(se_gate_fwd_kernel, dim3(B), dim3(256), lds, s, pool_part, splits, 1.0f / (float)HW, C, RD,
                            Wr, br, WeT, be, pooled, hpre, gate);
     }
     MIA_CHECK_LAUNCH("mia_se_gate_fwd");
@@ -957,20 +959,20 @@ extern "C" int mia_se_gate_bwd(const float* dgate_part, int B, int splits, int H
                   "mia_se_gate_bwd: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (se_wide(C, RD)) {
-        hipLaunchKernelGGL(se_prep_kernel, dim3(cdiv((long long)B * C, 256)), dim3(256), 0, s, dgate_part, splits, 0.f,
+        MIA_LAUNCH(se_prep_kernel, dim3(cdiv((long long)B * C, 256)), dim3(256), 0, s, dgate_part, splits, 0.f,
                            C, B * C, gate, 1, dpre2);
         const int waves = cdiv(RD, SE_JT) * cdiv(B, SE_IB);
-        hipLaunchKernelGGL(se_reduce_c_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, s, WeT, dpre2, B, C, RD,
+        MIA_LAUNCH(se_reduce_c_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, s, WeT, dpre2, B, C, RD,
                            (const float*)nullptr, hpre, 1, dpre1);
-        hipLaunchKernelGGL(se_expand_kernel, dim3(cdiv(C, 256), cdiv(B, SE_IB)), dim3(256), (size_t)RD * SE_IB * 4, s,
+        MIA_LAUNCH(se_expand_kernel, dim3(cdiv(C, 256), cdiv(B, SE_IB)), dim3(256), (size_t)RD * SE_IB * 4, s,
                            Wr, dpre1, B, C, RD, (const float*)nullptr, 1.0f / (float)HW, 1, dpool);
     } else {
         const size_t lds = (size_t)(C + RD) * 4;
-        hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(256), lds, s, dgate_part, splits, 1.0f / (float)HW, C, RD,
+        MIA_LAUNCH(se_gate_bwd_kernel, dim3(B), dim3(256), lds, s, dgate_part, splits, 1.0f / (float)HW, C, RD,
                            Wr, WeT, gate, hpre, dpre2, dpre1, dpool);
     }
     if (dWr)
-        hipLaunchKernelGGL(se_param_grad_kernel, dim3(cdiv((long long)C * RD, 64)), dim3(256), 0, s, B, C, RD, dpre2,
+        MIA_LAUNCH(se_param_grad_kernel, dim3(cdiv((long long)C * RD, 64)), dim3(256), 0, s, B, C, RD, dpre2,
                            dpre1, pooled, hpre, dWr, dbr, dWe, dbe);
     MIA_CHECK_LAUNCH("mia_se_gate_bwd");
     return 0;
@@ -980,7 +982,7 @@ extern "C" int mia_se_param_grad(int B, int C, int RD, const float* dpre2, const
                                  const float* hpre, float* dWr, float* dbr, float* dWe, float* dbe, void* stream) {
     MIA_CHECK_ARG(dpre2 && dpre1 && pooled && hpre && dWr && dbr && dWe && dbe && B > 0 && C > 0 && RD > 0,
                   "mia_se_param_grad: bad arguments");
-    hipLaunchKernelGGL(se_param_grad_kernel, dim3(cdiv((long long)C * RD, 64)), dim3(256), 0,
+    MIA_LAUNCH(se_param_grad_kernel, dim3(cdiv((long long)C * RD, 64)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), B, C, RD, dpre2, dpre1, pooled, hpre, dWr, dbr, dWe, dbe);
     MIA_CHECK_LAUNCH("mia_se_param_grad");
     return 0;
@@ -1059,10 +1061,10 @@ extern "C" int mia_bn_lin_prep(int dtype, const void* W, int Cm, int Cin, const 
     dim3 grid((unsigned)(nS + cdiv((long long)Cm * Cin, 256)));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(bn_lin_prep_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)W, Cm, Cin, ca, cb, cd,
+        MIA_LAUNCH(bn_lin_prep_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)W, Cm, Cin, ca, cb, cd,
                            (bf16_t*)WcaT, (bf16_t*)S, r, nS);
     else
-        hipLaunchKernelGGL(bn_lin_prep_kernel<float>, grid, dim3(256), 0, s, (const float*)W, Cm, Cin, ca, cb, cd,
+        MIA_LAUNCH(bn_lin_prep_kernel<float>, grid, dim3(256), 0, s, (const float*)W, Cm, Cin, ca, cb, cd,
                            (float*)WcaT, (float*)S, r, nS);
     MIA_CHECK_LAUNCH("mia_bn_lin_prep");
     return 0;
@@ -1075,9 +1077,9 @@ extern "C" int mia_bn_lin_fix(int dtype, const void* W, int Cm, int Cin, const f
     dim3 grid((unsigned)cdiv((long long)Cm * Cin, 256));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(bn_lin_fix_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)W, Cm, Cin, ca, cb, cd, G, cs, dW);
+        MIA_LAUNCH(bn_lin_fix_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)W, Cm, Cin, ca, cb, cd, G, cs, dW);
     else
-        hipLaunchKernelGGL(bn_lin_fix_kernel<float>, grid, dim3(256), 0, s, (const float*)W, Cm, Cin, ca, cb, cd, G, cs, dW);
+        MIA_LAUNCH(bn_lin_fix_kernel<float>, grid, dim3(256), 0, s, (const float*)W, Cm, Cin, ca, cb, cd, G, cs, dW);
     MIA_CHECK_LAUNCH("mia_bn_lin_fix");
     return 0;
 }
@@ -1119,10 +1121,10 @@ extern "C" int mia_stem_im2col(int dtype, const float* x, int B, int H, int W, v
     if (blocks > 16384) blocks = 16384;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, x, B, H, W, OH, OW,
+        MIA_LAUNCH(stem_im2col_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, x, B, H, W, OH, OW,
                            (bf16_t*)col);
     else
-        hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, x, B, H, W, OH, OW,
+        MIA_LAUNCH(stem_im2col_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, x, B, H, W, OH, OW,
                            (float*)col);
     MIA_CHECK_LAUNCH("mia_stem_im2col");
     return 0;
@@ -1158,10 +1160,10 @@ extern "C" int mia_cast_pad_transpose(int dtype, const float* src, int R, int Cc
     if (blocks > 8192) blocks = 8192;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(cast_pad_transpose_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, src, R, Cc,
+        MIA_LAUNCH(cast_pad_transpose_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, src, R, Cc,
                            (bf16_t*)dst, ldd, (bf16_t*)dstT, ldt);
     else
-        hipLaunchKernelGGL(cast_pad_transpose_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, src, R, Cc,
+        MIA_LAUNCH(cast_pad_transpose_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, src, R, Cc,
                            (float*)dst, ldd, (float*)dstT, ldt);
     MIA_CHECK_LAUNCH("mia_cast_pad_transpose");
     return 0;
@@ -1229,9 +1231,9 @@ extern "C" int mia_cast_pad_transpose_multi(int dtype, int n, const void* const*
         }
         ch.first_block[ch.n] = blocks;
         if (dtype == MIA_BF16)
-            hipLaunchKernelGGL(cast_pad_transpose_multi_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, ch);
+            MIA_LAUNCH(cast_pad_transpose_multi_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, ch);
         else
-            hipLaunchKernelGGL(cast_pad_transpose_multi_kernel<float>, dim3(blocks), dim3(256), 0, s, ch);
+            MIA_LAUNCH(cast_pad_transpose_multi_kernel<float>, dim3(blocks), dim3(256), 0, s, ch);
     }
     MIA_CHECK_LAUNCH("mia_cast_pad_transpose_multi");
     return 0;

@@ -166,7 +166,7 @@ extern "C" int mia_resize_normalize_u8(const uint8_t* src, int N, int h, int w, 
     const long long lds = (long long)ow * 16 + RZ_ROWS * 16 + src_rows * (long long)w * ch + 16;
     if (lds <= 64 * 1024 && N <= 65535 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
         dim3 grid((unsigned)((oh + RZ_ROWS - 1) / RZ_ROWS), (unsigned)N);
-        hipLaunchKernelGGL(resize_normalize_tile_kernel, grid, dim3(256), (size_t)lds,
+        MIA_LAUNCH(resize_normalize_tile_kernel, grid, dim3(256), (size_t)lds,
                            reinterpret_cast<hipStream_t>(stream), src, h, w, ch, dst, oh, ow, m[0], m[1], m[2], r[0], r[1],
                            r[2], mode);
         MIA_CHECK_LAUNCH("mia_resize_normalize_u8");
@@ -175,7 +175,7 @@ extern "C" int mia_resize_normalize_u8(const uint8_t* src, int N, int h, int w, 
     const long long total = (long long)N * oh * ow;
     long long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(resize_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0,
+    MIA_LAUNCH(resize_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), src, N, h, w, ch, dst, oh, ow, m[0], m[1], m[2], r[0],
                        r[1], r[2], mode);
     MIA_CHECK_LAUNCH("mia_resize_normalize_u8");
@@ -211,7 +211,7 @@ extern "C" int mia_resize_u8(const uint8_t* src, int N, int h, int w, int ch, ui
     MIA_CHECK_ARG(ch == 1 || ch == 3, "mia_resize_u8: channels must be 1 or 3, got %d", ch);
     long long blocks = ((long long)N * oh * ow + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(resize_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src,
+    MIA_LAUNCH(resize_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src,
                        N, h, w, ch, dst, oh, ow);
     MIA_CHECK_LAUNCH("mia_resize_u8");
     return 0;
@@ -285,6 +285,132 @@ __global__ __launch_bounds__(256) void slice_compact_kernel(const int* flags, lo
     if (tid == 0) count[0] = base_s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// One launch for slices a single workgroup can scan (the configured volumes: 256x256 slices, 32..512 of them, where
+// three launches -- zero fill, OR-reduce, compaction -- were a fixed 23 us whatever N): workgroup z scans slice z
+// and stores its flag word (no zero fill, no atomic OR), then takes a ticket; the workgroup that draws the last ticket
+// runs the compaction over all flag words and puts the ticket counter back to zero.
+//
+// Hand-over between workgroups (they may sit on different XCDs, whose L2 caches are not coherent with each other for
+// ordinary accesses): the flag word is stored and loaded with agent scope, the ticket is an agent-scope
+// acquire-release read-modify-write issued by the thread that stored the flag, and every thread of the last
+// workgroup passes an agent-scope acquire fence before it reads flag words. The kernel itself writes nothing else
+// before the ticket, so the release has no dirty lines to write back.
+//
+// Ticket counters live in a zero-initialised device array built into the library; each call takes the next of 64
+// slots, so calls on different streams of one GPU do not share a counter unless more than 64 are in flight at once.
+// ------------------------------------------------------------------------------------------------
+#define MIA_ZSF_TICKETS 64
+static __device__ __align__(256) unsigned zsf_tickets[MIA_ZSF_TICKETS];
+static unsigned* g_ticket_ptr[64];
+static unsigned g_ticket_next[64];
+static std::mutex g_ticket_mu;
+
+// -> device address of the ticket slot for this call (nullptr + error message on failure)
+static unsigned* zsf_ticket_slot() {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= 64) {
+        mia_set_error("mia_zero_slice_filter: hipGetDevice failed or device %d out of range: %s", dev, hipGetErrorString(e));
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_ticket_mu);
+    if (!g_ticket_ptr[dev]) {
+        unsigned* ptr = nullptr;
+        e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(zsf_tickets));
+        if (e != hipSuccess || !ptr) {
+            mia_set_error("mia_zero_slice_filter: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+            return nullptr;
+        }
+        g_ticket_ptr[dev] = ptr;
+    }
+    return g_ticket_ptr[dev] + (g_ticket_next[dev]++ % MIA_ZSF_TICKETS);
+}
+
+__global__ __launch_bounds__(256) void slice_filter_fused_kernel(const uint8_t* __restrict__ vol, long long slice_bytes,
+                                                                 int kind, int* flags, unsigned* ticket, int N,
+                                                                 uint8_t* __restrict__ keep, int* __restrict__ idx,
+                                                                 int* __restrict__ count) {
+    __shared__ int wsum[4];
+    __shared__ int base_s, last_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long z = blockIdx.x;
+    const uint8_t* base = vol + z * slice_bytes;
+    const uint32_t fmask = kind == 1 ? 0x7fffffffu : 0xffffffffu;
+    uint32_t acc = 0;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(base);
+    long long head = (16 - (long long)(addr & 15)) & 15;
+    if (head > slice_bytes) head = slice_bytes;
+    const long long body = (slice_bytes - head) / 16;
+    const uint4* vb = reinterpret_cast<const uint4*>(base + head);
+    long long i = tid;
+    // eight independent 16-byte loads in flight per lane
+    for (; i + 7 * 256 < body; i += 8 * 256) {
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        v4u v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(vb + i + u * 256));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc |= (v[u].x & fmask) | (v[u].y & fmask) | (v[u].z & fmask) | (v[u].w & fmask);
+    }
+    for (; i < body; i += 256) {
+        const uint4 v = vb[i];
+        acc |= (v.x & fmask) | (v.y & fmask) | (v.z & fmask) | (v.w & fmask);
+    }
+    {
+        // head [0, head) and tail [tail_begin, slice_bytes): fewer than 32 bytes in total, element-wise
+        const long long tail_begin = head + body * 16;
+        const int esz = kind == 1 ? 4 : 1;
+        for (long long o = (long long)tid * esz; o < head; o += 256 * esz) {
+            if (kind == 1) acc |= (*reinterpret_cast<const uint32_t*>(base + o)) & fmask;
+            else acc |= base[o];
+        }
+        for (long long o = tail_begin + (long long)tid * esz; o < slice_bytes; o += 256 * esz) {
+            if (kind == 1) acc |= (*reinterpret_cast<const uint32_t*>(base + o)) & fmask;
+            else acc |= base[o];
+        }
+    }
+    const unsigned long long any = __ballot(acc != 0);
+    if (lane == 0) wsum[wave] = any != 0ull;
+    __syncthreads();
+    if (tid == 0) {
+        const int f = wsum[0] | wsum[1] | wsum[2] | wsum[3];
+        __hip_atomic_store(flags + z, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = (t == gridDim.x - 1);
+        base_s = 0;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    // ---- the last workgroup to arrive: every flag word has been stored and released before its ticket was drawn
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int z0 = 0; z0 < N; z0 += 256) {
+        const int zz = z0 + tid;
+        const int f = (zz < N) ? (__hip_atomic_load(flags + zz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) : 0;
+        const unsigned long long bal = __ballot(f);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wave; ++k) woff += wsum[k];
+        const int b0 = base_s;
+        if (zz < N) {
+            keep[zz] = (uint8_t)f;
+            if (f) idx[b0 + woff + before] = zz;
+        }
+        __syncthreads();
+        if (tid == 0) base_s = b0 + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        count[0] = base_s;
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the slot's next call
+    }
+}
+
+// slices up to this size are scanned by one workgroup each (one launch); larger ones are split over several
+#define MIA_ZSF_FUSED_MAX_SLICE_BYTES (1ll << 20)
+
 extern "C" int mia_zero_slice_filter(const void* vol, int elem_bytes, int is_float, long long n_slices,
                                      long long slice_elems, int* flags_ws, uint8_t* keep, int* idx, int* count,
                                      void* stream) {
@@ -293,15 +419,23 @@ extern "C" int mia_zero_slice_filter(const void* vol, int elem_bytes, int is_flo
     MIA_CHECK_ARG((elem_bytes == 1 || elem_bytes == 2 || elem_bytes == 4) && (!is_float || elem_bytes == 4),
                   "mia_zero_slice_filter: unsupported element type (%d bytes, float=%d)", elem_bytes, is_float);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long long slice_bytes = slice_elems * elem_bytes;
+    if (slice_bytes <= MIA_ZSF_FUSED_MAX_SLICE_BYTES) {
+        unsigned* ticket = zsf_ticket_slot();
+        if (!ticket) return -3;
+        MIA_LAUNCH(slice_filter_fused_kernel, dim3((unsigned)n_slices), dim3(256), 0, s, (const uint8_t*)vol,
+                           slice_bytes, is_float ? 1 : 0, flags_ws, ticket, (int)n_slices, keep, idx, count);
+        MIA_CHECK_LAUNCH("mia_zero_slice_filter");
+        return 0;
+    }
     hipError_t e = mia_zero_words(flags_ws, n_slices, s);
     MIA_CHECK_ARG(e == hipSuccess, "mia_zero_slice_filter: zero fill failed: %s", hipGetErrorString(e));
-    const long long slice_bytes = slice_elems * elem_bytes;
     long long splits = slice_bytes / (16 * 256 * 8);  // >= 8 vector loads per thread
     if (splits < 1) splits = 1;
     if (splits > 64) splits = 64;
-    hipLaunchKernelGGL(slice_nonzero_kernel, dim3((unsigned)splits, (unsigned)n_slices), dim3(256), 0, s,
+    MIA_LAUNCH(slice_nonzero_kernel, dim3((unsigned)splits, (unsigned)n_slices), dim3(256), 0, s,
                        (const uint8_t*)vol, slice_bytes, is_float ? 1 : 0, flags_ws);
-    hipLaunchKernelGGL(slice_compact_kernel, dim3(1), dim3(256), 0, s, flags_ws, n_slices, keep, idx, count);
+    MIA_LAUNCH(slice_compact_kernel, dim3(1), dim3(256), 0, s, flags_ws, n_slices, keep, idx, count);
     MIA_CHECK_LAUNCH("mia_zero_slice_filter");
     return 0;
 }
@@ -340,6 +474,27 @@ static int* zsf_scratch_ptr() {
         g_scratch_ptr[dev] = ptr;
     }
     return g_scratch_ptr[dev];
+}
+
+// Resolves the built-in arrays' addresses on the current device. Called from mia_check_device(), so a process that
+// checks its device at start-up (as the Python package's users do) never meets the first-use symbol lookup -- which
+// may load the code object and takes a host lock -- inside a HIP graph capture.
+int mia_preprocess_init_device() {
+    if (!zsf_scratch_ptr()) return -3;
+    {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -3;
+        std::lock_guard<std::mutex> lock(g_ticket_mu);
+        if (!g_ticket_ptr[dev]) {
+            unsigned* ptr = nullptr;
+            if (hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(zsf_tickets)) != hipSuccess || !ptr) {
+                mia_set_error("mia_check_device: hipGetSymbolAddress(zsf_tickets) failed on device %d", dev);
+                return -3;
+            }
+            g_ticket_ptr[dev] = ptr;
+        }
+    }
+    return 0;
 }
 
 extern "C" int mia_zero_slice_filter_static(const void* vol, int elem_bytes, int is_float, long long n_slices,
@@ -384,7 +539,7 @@ extern "C" int mia_gather_slices(const void* vol, int elem_bytes, long long n_sl
     long long chunks = slice_bytes / (16 * 256 * 4);
     if (chunks < 1) chunks = 1;
     if (chunks > 64) chunks = 64;
-    hipLaunchKernelGGL(gather_slices_kernel, dim3((unsigned)chunks, (unsigned)n_slices), dim3(256), 0,
+    MIA_LAUNCH(gather_slices_kernel, dim3((unsigned)chunks, (unsigned)n_slices), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), (const uint8_t*)vol, slice_bytes, idx, count,
                        (uint8_t*)out);
     MIA_CHECK_LAUNCH("mia_gather_slices");

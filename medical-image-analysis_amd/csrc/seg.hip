@@ -53,10 +53,10 @@ extern "C" int mia_im2col3x3(int dtype, const void* x, int B, int H, int W, int 
     const long long total = (long long)B * H * W * 9 * (C / 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(im2col3_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)x, B, H, W, C,
+        MIA_LAUNCH(im2col3_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)x, B, H, W, C,
                            scale, shift, act, gate, (bf16_t*)col);
     else
-        hipLaunchKernelGGL(im2col3_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, B, H, W, C,
+        MIA_LAUNCH(im2col3_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, B, H, W, C,
                            scale, shift, act, gate, (float*)col);
     MIA_CHECK_LAUNCH("mia_im2col3x3");
     return 0;
@@ -89,10 +89,10 @@ extern "C" int mia_col2im3x3(int dtype, const void* dcol, int B, int H, int W, i
     const long long total = (long long)B * H * W * (C / 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(col2im3_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dcol, B, H, W,
+        MIA_LAUNCH(col2im3_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dcol, B, H, W,
                            C, (bf16_t*)dx);
     else
-        hipLaunchKernelGGL(col2im3_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)dcol, B, H, W, C,
+        MIA_LAUNCH(col2im3_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)dcol, B, H, W, C,
                            (float*)dx);
     MIA_CHECK_LAUNCH("mia_col2im3x3");
     return 0;
@@ -154,10 +154,10 @@ extern "C" int mia_upsample_concat_fwd(int dtype, const void* x, int B, int h, i
     const long long total = (long long)B * H * W * ((C1 + C2) / 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(upsample_concat_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)x, B, h,
+        MIA_LAUNCH(upsample_concat_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)x, B, h,
                            w, C1, (const bf16_t*)skip, C2, H, W, (bf16_t*)out);
     else
-        hipLaunchKernelGGL(upsample_concat_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, B, h, w,
+        MIA_LAUNCH(upsample_concat_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, B, h, w,
                            C1, (const float*)skip, C2, H, W, (float*)out);
     MIA_CHECK_LAUNCH("mia_upsample_concat_fwd");
     return 0;
@@ -215,10 +215,10 @@ extern "C" int mia_upsample_concat_bwd(int dtype, const void* dout, int B, int h
     const long long total = (long long)B * h * w * (C1 / 4) + (long long)B * H * W * (C2 / 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIA_BF16)
-        hipLaunchKernelGGL(upsample_concat_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dout,
+        MIA_LAUNCH(upsample_concat_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dout,
                            B, h, w, C1, C2, H, W, (bf16_t*)dx, (bf16_t*)dskip);
     else
-        hipLaunchKernelGGL(upsample_concat_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)dout, B,
+        MIA_LAUNCH(upsample_concat_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)dout, B,
                            h, w, C1, C2, H, W, (float*)dx, (float*)dskip);
     MIA_CHECK_LAUNCH("mia_upsample_concat_bwd");
     return 0;
@@ -344,10 +344,10 @@ extern "C" int mia_pixel_linear_fwd(int dtype, const void* x, int B, int HW, int
     auto go = [&](auto nc_tag) {
         constexpr int NC_ = decltype(nc_tag)::value;
         if (dtype == MIA_BF16)
-            hipLaunchKernelGGL((pixel_linear_fwd_kernel<bf16_t, NC_>), dim3(g), dim3(256), 0, s, (const bf16_t*)x, B, HW, C, n, Wt,
+            MIA_LAUNCH((pixel_linear_fwd_kernel<bf16_t, NC_>), dim3(g), dim3(256), 0, s, (const bf16_t*)x, B, HW, C, n, Wt,
                                bias, logits);
         else
-            hipLaunchKernelGGL((pixel_linear_fwd_kernel<float, NC_>), dim3(g), dim3(256), 0, s, (const float*)x, B, HW, C, n, Wt, bias,
+            MIA_LAUNCH((pixel_linear_fwd_kernel<float, NC_>), dim3(g), dim3(256), 0, s, (const float*)x, B, HW, C, n, Wt, bias,
                                logits);
     };
     if (n <= 8) go(std::integral_constant<int, 8>{});
@@ -367,14 +367,14 @@ extern "C" int mia_pixel_linear_bwd(int dtype, const void* x, const float* dlogi
     auto go = [&](auto nc_tag) {
         constexpr int NC_ = decltype(nc_tag)::value;
         if (dtype == MIA_BF16) {
-            hipLaunchKernelGGL((pixel_linear_bwd_data_kernel<bf16_t, NC_>), dim3(g), dim3(256), 0, s, dlogits, B, HW, C, n, Wt,
+            MIA_LAUNCH((pixel_linear_bwd_data_kernel<bf16_t, NC_>), dim3(g), dim3(256), 0, s, dlogits, B, HW, C, n, Wt,
                                (bf16_t*)dx);
-            hipLaunchKernelGGL((pixel_linear_bwd_weight_kernel<bf16_t, NC_>), dim3(partial_rows), dim3(256), 0, s, (const bf16_t*)x,
+            MIA_LAUNCH((pixel_linear_bwd_weight_kernel<bf16_t, NC_>), dim3(partial_rows), dim3(256), 0, s, (const bf16_t*)x,
                                dlogits, B, HW, C, n, partial);
         } else {
-            hipLaunchKernelGGL((pixel_linear_bwd_data_kernel<float, NC_>), dim3(g), dim3(256), 0, s, dlogits, B, HW, C, n, Wt,
+            MIA_LAUNCH((pixel_linear_bwd_data_kernel<float, NC_>), dim3(g), dim3(256), 0, s, dlogits, B, HW, C, n, Wt,
                                (float*)dx);
-            hipLaunchKernelGGL((pixel_linear_bwd_weight_kernel<float, NC_>), dim3(partial_rows), dim3(256), 0, s, (const float*)x,
+            MIA_LAUNCH((pixel_linear_bwd_weight_kernel<float, NC_>), dim3(partial_rows), dim3(256), 0, s, (const float*)x,
                                dlogits, B, HW, C, n, partial);
         }
     };
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void channel_dropout_mask_kernel(float* mask, 
 extern "C" int mia_channel_dropout_mask(float* mask, int B, int C, float p, unsigned long long seed,
                                         const unsigned long long* seed_offset, void* stream) {
     MIA_CHECK_ARG(mask && B > 0 && C > 0 && p >= 0.f && p < 1.f, "mia_channel_dropout_mask: bad arguments");
-    hipLaunchKernelGGL(channel_dropout_mask_kernel, dim3(cdiv((long long)B * C, 256)), dim3(256), 0,
+    MIA_LAUNCH(channel_dropout_mask_kernel, dim3(cdiv((long long)B * C, 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), mask, B * C, p, seed, seed_offset);
     MIA_CHECK_LAUNCH("mia_channel_dropout_mask");
     return 0;
@@ -567,12 +567,12 @@ extern "C" int mia_seg_loss_fwd(const float* logits, const long long* target, in
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     auto go = [&](auto nc_tag) {
         constexpr int NC_ = decltype(nc_tag)::value;
-        hipLaunchKernelGGL(seg_loss_sums_kernel<NC_>, dim3(B * splits), dim3(256), 0, s, logits, target, HW, n, splits,
+        MIA_LAUNCH(seg_loss_sums_kernel<NC_>, dim3(B * splits), dim3(256), 0, s, logits, target, HW, n, splits,
                            class_weights, partial);
     };
     if (n <= 8) go(std::integral_constant<int, 8>{});
     else go(std::integral_constant<int, 32>{});
-    hipLaunchKernelGGL(seg_loss_finalize_kernel, dim3(1), dim3(256), 0, s, partial, B, n, splits, iou, smooth, ce_weight,
+    MIA_LAUNCH(seg_loss_finalize_kernel, dim3(1), dim3(256), 0, s, partial, B, n, splits, iou, smooth, ce_weight,
                        overlap_weight, loss, coef);
     MIA_CHECK_LAUNCH("mia_seg_loss_fwd");
     return 0;
@@ -585,7 +585,7 @@ extern "C" int mia_seg_loss_bwd(const float* logits, const long long* target, in
     MIA_CHECK_ARG(n > 0 && n <= SEG_MAXN, "mia_seg_loss_bwd: classes must be 1..%d (got %d)", SEG_MAXN, n);
     auto go = [&](auto nc_tag) {
         constexpr int NC_ = decltype(nc_tag)::value;
-        hipLaunchKernelGGL(seg_loss_bwd_kernel<NC_>, dim3(grid_for((long long)B * HW, 4096)), dim3(256), 0,
+        MIA_LAUNCH(seg_loss_bwd_kernel<NC_>, dim3(grid_for((long long)B * HW, 4096)), dim3(256), 0,
                            reinterpret_cast<hipStream_t>(stream), logits, target, B, HW, n, class_weights, coef, upstream,
                            dlogits);
     };
@@ -705,10 +705,10 @@ extern "C" int mia_ce_general_fwd(const float* logits, long long stride_image, l
                       partial_rows <= 4096,
                   "mia_ce_general_fwd: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(ce_general_fwd_kernel, dim3(partial_rows), dim3(256), 0, s, logits, stride_image, stride_class,
+    MIA_LAUNCH(ce_general_fwd_kernel, dim3(partial_rows), dim3(256), 0, s, logits, stride_image, stride_class,
                        stride_pos, target, images * positions, positions, n, class_weights, focal, alpha, gamma, per_elem,
                        partial);
-    hipLaunchKernelGGL(ce_general_finalize_kernel, dim3(1), dim3(256), 0, s, partial, partial_rows, mean, out);
+    MIA_LAUNCH(ce_general_finalize_kernel, dim3(1), dim3(256), 0, s, partial, partial_rows, mean, out);
     MIA_CHECK_LAUNCH("mia_ce_general_fwd");
     return 0;
 }
@@ -719,7 +719,7 @@ extern "C" int mia_ce_general_bwd(const float* logits, long long stride_image, l
                                   const float* out, const float* upstream, int upstream_per_elem, float* dlogits,
                                   void* stream) {
     MIA_CHECK_ARG(logits && target && dlogits && images > 0 && positions > 0 && n > 0, "mia_ce_general_bwd: bad arguments");
-    hipLaunchKernelGGL(ce_general_bwd_kernel, dim3(grid_for(images * positions, 4096)), dim3(256), 0,
+    MIA_LAUNCH(ce_general_bwd_kernel, dim3(grid_for(images * positions, 4096)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), logits, stride_image, stride_class, stride_pos, target,
                        images * positions, positions, n, class_weights, focal, alpha, gamma, out, upstream,
                        upstream_per_elem, dlogits);

@@ -119,30 +119,54 @@ class GradReducer:
         while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
             self._launch(self.buckets[self._next])
 
+    # read by ops.Side.usable: this hook never reads a gradient on the caller's stream before the streams are joined
+    _hook._mia_side_aware = True
+
     def _launch(self, b):
-        # one fused multi-tensor copy packs the bucket, then its all-reduce starts while backward continues
+        """Pack the bucket with one fused multi-tensor copy and start its all-reduce while backward continues.
+
+        On the GPU the weight gradients are computed on ops.Side's second stream, so the pack and the collective are
+        queued THERE (the side stream first waits for what the caller's stream has queued so far, which covers the
+        gradients computed on it): the caller's stream -- the data-gradient chain of the backward pass -- never
+        waits for a weight-gradient kernel because of a bucket. It meets the exchange again in finish(), where it
+        waits for the collectives, and at the end of the backward pass, where it joins the side stream anyway."""
         ready = b["ready"]
-        if ready:
-            if ready[0].is_cuda:
-                from .ops import Side
-                Side.sync()     # weight gradients computed on the side stream are complete before they are packed
-            views = [b["views"][id(p)] for p in ready]
-            torch._foreach_copy_(views, [p.grad for p in ready])
-            for p, v in zip(ready, views):
-                p.grad = v
-        b["ready"] = []
+        cuda = b["flat"].is_cuda
+        if cuda:
+            from .ops import Side, _Inline
+            scope = Side(b["flat"].device) if Side.enabled else _Inline()
+        else:
+            import contextlib
+            scope = contextlib.nullcontext()
         b["launched"] = True
         assert b["index"] == self._next, "buckets go out in index order"
         self._next += 1
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         _trace(f"launch bucket {b['index']} ({b['flat'].numel()} elements, {len(ready)} gradients packed)")
-        buf = b["flat"]
-        if self._host_staged and buf.is_cuda:
-            if "host" not in b:
-                b["host"] = torch.empty(buf.shape, dtype=buf.dtype, pin_memory=True)
-            buf = b["host"]
-            buf.copy_(b["flat"])        # blocking copy: the gradients packed above have been computed when it returns
-        self._works.append((dist.all_reduce(buf, op=op, group=self.group, async_op=True), b))
+        with scope:
+            if len(ready) < b["count"]:
+                # parameters without a gradient on this rank contribute zeros; their slots still hold the last
+                # exchange's result. Every other slot is overwritten by the pack, so nothing else is cleared
+                got = {id(p) for p in ready}
+                torch._foreach_zero_([v for k, v in b["views"].items() if k not in got])
+            if ready:
+                views = [b["views"][id(p)] for p in ready]
+                grads = [p.grad for p in ready]
+                torch._foreach_copy_(views, grads)
+                for p, v in zip(ready, views):
+                    p.grad = v
+                # the unpacked gradient tensors stay referenced until finish(): their memory (some of it from the
+                # caller's stream's pool) must not be handed out again before the pack, queued elsewhere, has read it
+                b["held"] = grads
+            b["ready"] = []
+            buf = b["flat"]
+            if self._host_staged and buf.is_cuda:
+                if "host" not in b:
+                    b["host"] = torch.empty(buf.shape, dtype=buf.dtype, pin_memory=True)
+                buf = b["host"]
+                buf.copy_(b["flat"])    # blocking copy: the gradients packed above have been computed when it returns
+            # c10d orders the collective after the work queued on the CURRENT stream, here the one that packed
+            self._works.append((dist.all_reduce(buf, op=op, group=self.group, async_op=True), b))
 
     def finish(self):
         """Launch the buckets that are not out yet, wait for all of them."""
@@ -151,11 +175,12 @@ class GradReducer:
             while self._next < len(self.buckets):
                 self._launch(self.buckets[self._next])
             for w, b in self._works:
-                w.wait()
+                w.wait()        # the caller's stream waits for the collective (and with it for the pack before it)
                 if self._host_staged and b["flat"].is_cuda:
                     b["flat"].copy_(b["host"])
                 if not self._avg:
                     b["flat"].div_(self.world)
+                b.pop("held", None)
             _trace(f"finish exit ({len(self._works)} buckets exchanged)")
         self._works.clear()
         self._in_backward = False
@@ -166,11 +191,8 @@ class GradReducer:
             b["ready"] = []
 
     def zero_grad(self):
-        """Drop last step's gradients; with an exchange also clear the flat buckets (slots of parameters that
-        receive no gradient must contribute zeros to the reduction)."""
-        if self.exchange:
-            for b in self.buckets:
-                b["flat"].zero_()
+        """Drop last step's gradients. The flat buckets are not cleared: a bucket's pack overwrites the slot of every
+        parameter that received a gradient, and _launch zeroes the slots of those that did not."""
         for p in self.params:
             p.grad = None
 

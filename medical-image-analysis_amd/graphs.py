@@ -68,13 +68,18 @@ class GraphedTrainStep:
     Construction runs `warmup` eager steps on the example batch and then puts the model, its BatchNorm buffers and
     the optimizer state back as they were, so a graphed run starts from the same point as an eager one. Dropout masks
     are drawn from torch's CPU generator state at every replay (reproducible under torch.manual_seed) but are not
-    the same masks an eager step would draw. Single process only: gradients are not all-reduced inside the graph."""
+    the same masks an eager step would draw. Single process only: gradients are not all-reduced inside the graph.
+
+    fork=True (default) captures the weight-gradient kernels on ops.Side's second stream, as the eager step runs them:
+    the fork and join events become edges of the graph, so a replay runs the two branches side by side. The capture
+    stream is a stream of this object's own, used for the warm-up steps as well, so the stream pair exists before the
+    capture begins. fork=False records everything on one stream."""
 
     WORDS = 64           # device words: [0:2] seed offset (uint64), [4:] AdamW rows of 4 floats
     MAX_ROWS = (WORDS - 4) // 4
 
     def __init__(self, model, task: str, dataset_name: str, criterion, optimizer, example_input: torch.Tensor,
-                 example_target: torch.Tensor, warmup: int = 2):
+                 example_target: torch.Tensor, warmup: int = 2, fork: bool = True):
         from .optim import AdamW
         if not model.training:
             raise RuntimeError("GraphedTrainStep captures the train-mode step: call model.train() first")
@@ -107,24 +112,34 @@ class GraphedTrainStep:
             optimizer.step()
             return out, loss
 
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):      # allocates the optimizer state, sizes the pools, loads every kernel
-                one_step()
-        torch.cuda.current_stream(dev).wait_stream(side)
-
-        self.graph = torch.cuda.CUDAGraph()
-        optimizer.zero_grad(set_to_none=True)
-        ops.Replay.seed_off = self.words.data_ptr()
-        optimizer.begin_capture(self.words.data_ptr() + 16, self.MAX_ROWS)
+        self.fork = bool(fork) and ops.Side.enabled
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        side_was = ops.Side.enabled
+        ops.Side.enabled = self.fork
         try:
-            with torch.cuda.graph(self.graph):
-                self.outputs, self.loss = one_step()
+            with torch.cuda.stream(cap):
+                for _ in range(max(1, warmup)):  # allocates the optimizer state, sizes the pools, loads every kernel
+                    one_step()
+            torch.cuda.current_stream(dev).wait_stream(cap)
+            torch.cuda.synchronize(dev)
+
+            self.graph = torch.cuda.CUDAGraph()
+            optimizer.zero_grad(set_to_none=True)
+            ops.Replay.seed_off = self.words.data_ptr()
+            optimizer.begin_capture(self.words.data_ptr() + 16, self.MAX_ROWS)
+            ops.Side.capture_ok = self.fork
+            try:
+                with torch.cuda.graph(self.graph, stream=cap):
+                    self.outputs, self.loss = one_step()
+                    ops.Side.sync()     # a capture may only end with every forked branch joined (a no-op after AdamW.step)
+            finally:
+                ops.Side.capture_ok = False
+                ops.Replay.seed_off = None
+                self.rows = optimizer.end_capture()
         finally:
-            ops.Replay.seed_off = None
-            self.rows = optimizer.end_capture()
-    
+            ops.Side.enabled = side_was
+
         # ---- put everything back: neither the warm-up steps nor the capture count as training
         with torch.no_grad():
             for t, s0 in zip(tensors, saved):
@@ -162,5 +177,6 @@ class GraphedTrainStep:
         for i, w in enumerate(packed):
             buf[4 + i] = w
         lib().mia_set_words(self.words.data_ptr(), n, buf, ops._stream())
+        ops.WeightEpoch.bump()      # the replayed kernels rewrite parameters and BatchNorm buffers in place
         self.graph.replay()
         return self.loss.clone() if copy_out else self.loss

@@ -51,6 +51,18 @@ def seed_offset():
     return Replay.seed_off
 
 
+class WeightEpoch:
+    """Counts the events that change parameters or BatchNorm running statistics through raw device pointers, which
+    torch's tensor version counters never see: a train-mode BatchNorm finalize (running_mean / running_var), the HIP
+    AdamW step, a replay of a captured training step. Caches derived from the weights (the BatchNorm-folded inference
+    copies of the trunk) carry the count they were built at and are rebuilt when it has moved."""
+    n = 0
+
+    @classmethod
+    def bump(cls):
+        cls.n += 1
+
+
 def _require_cuda(t: torch.Tensor):
     if not t.is_cuda:
         raise RuntimeError("mia_amd kernels need tensors on an MI355X device; there is no CPU path")
@@ -78,9 +90,14 @@ class Side:
       * the main stream waits for the side stream (Side.sync) at the end of the backward pass (an autograd engine
         callback queued by every block), before a gradient bucket is packed (ddp.GradReducer) and at the top of
         AdamW.step(); code that reads .grad from inside a backward hook must call Side.sync() itself;
-      * Side.usable(params) is False, and the caller then stays on its own stream, while a HIP graph is being captured,
-        when Side.enabled is off, or when one of the parameters already holds a gradient (autograd would add to it on
-        the main stream at once)."""
+      * Side.usable(params) is False, and the caller then stays on its own stream, when Side.enabled is off, when one
+        of the parameters already holds a gradient (autograd would add to it on the main stream at once), when a
+        parameter carries a tensor hook or a post-accumulate hook that is not marked `_mia_side_aware` (such a hook
+        would read the gradient on the main stream before the join), or when a parameter has more than one use in the
+        graphs alive at this moment (autograd would add the uses' gradients together on the main stream). A hook
+        that waits for the side stream itself (ddp.GradReducer's) sets `_mia_side_aware = True` on its function.
+      * Under HIP-graph capture the fork/join events are captured like any others: the side stream joins the capture
+        at its first wait and must be joined back (Side.sync) before the capture ends; graphs.GraphedTrainStep does."""
     enabled = True
     MIN_WORK = 8_000_000   # elements of the block's expanded tensor below which its weight gradients stay on the main stream
     depth = 0          # > 0 while launches go to a side stream (inside a `with Side(...)` block)
@@ -88,11 +105,51 @@ class Side:
     _pending = {}      # (device index, main stream id) -> (main, side) with side work the main stream has not waited for
     _callback_task = -1        # autograd graph task that already has the join queued (one callback per backward pass)
 
+    capture_ok = False  # set by graphs.GraphedTrainStep around its capture: the fork is recorded into the graph
+    _uses = {}          # id(parameter) -> [uses in live graphs, "had more than one use at a time" flag]
+
     @classmethod
     def usable(cls, params=()) -> bool:
-        if not cls.enabled or torch.cuda.is_current_stream_capturing():
+        if not cls.enabled or (not cls.capture_ok and torch.cuda.is_current_stream_capturing()):
             return False
-        return all(p is None or p.grad is None for p in params)
+        for p in params:
+            if p is None:
+                continue
+            if p.grad is not None or p._backward_hooks:
+                return False
+            post = getattr(p, "_post_accumulate_grad_hooks", None)
+            if post and not all(getattr(fn, "_mia_side_aware", False) for fn in post.values()):
+                return False
+            u = cls._uses.get(id(p))
+            if u is not None and u[1]:
+                return False
+        return True
+
+    class Use:
+        """Held by an autograd context for as long as its graph lives: counts the live uses of each parameter whose
+        gradient the context's backward would compute on the side stream."""
+        __slots__ = ("keys",)
+
+        def __init__(self, params):
+            self.keys = [id(p) for p in params if p is not None]
+            for k in self.keys:
+                u = Side._uses.setdefault(k, [0, False])
+                u[0] += 1
+                if u[0] > 1:
+                    u[1] = True
+
+        def release(self):
+            """Called at the end of the context's backward (the graph node itself may live on for as long as the
+            caller holds the loss tensor), and again, as a no-op, when the context is collected."""
+            for k in self.keys:
+                u = Side._uses.get(k)
+                if u is not None:
+                    u[0] -= 1
+                    if u[0] <= 0:
+                        del Side._uses[k]
+            self.keys = ()
+
+        __del__ = release
 
     def __init__(self, device, reads=()):
         self.main = torch.cuda.current_stream(device)
@@ -154,7 +211,8 @@ def side_scope(device, params, reads, work=None):
     a few microseconds cannot hide (eager step at batch 8: 20.0 ms forking everywhere, 15.6 ms on one stream)."""
     if work is not None and work < Side.MIN_WORK:
         return _Inline()
-    return Side(device, reads) if Side.usable(params) else _Inline()
+    ok = params if isinstance(params, bool) else Side.usable(params)   # a block's backward asks once and passes the answer
+    return Side(device, reads) if ok else _Inline()
 
 
 class KernelTimer:
@@ -282,6 +340,8 @@ def bn_finalize_fwd(part, count, bn: BNState, conv_bias=None):
     dev = bn.weight.device
     out = torch.empty((4, C), dtype=torch.float32, device=dev)
     P = part.shape[0] if part is not None else 0
+    if bn.training and bn.running_mean is not None:
+        WeightEpoch.bump()      # the kernel updates the running statistics in place
     lib().mia_bn_finalize_fwd(_p(part), P, C, float(count), _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
                               _p(bn.running_var), _p(bn.nbt), float(bn.momentum), float(bn.eps),
                               1 if bn.training else 0, _p(conv_bias), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]),
@@ -298,17 +358,23 @@ def bn_finalize_bwd(part, count, gamma, stats, training):
     return coef
 
 
-def bn_act_bwd_reduce(g, y, stats, act, *, gate=None, dpool=None, rows_per_img=0):
-    """In place on g; returns partials."""
+def bn_act_bwd_reduce(g, y, stats, act, *, gate=None, dpool=None, rows_per_img=0, out=None):
+    """-> (g', partials) with g' = (g*gate + dpool) * act'(bn(y)). g' goes to `out` (default: a fresh tensor; pass
+    out=g to update in place when the caller owns g -- an incoming autograd gradient is NOT the caller's to change).
+    With neither activation nor gate nor dpool g' is g itself and nothing is written."""
     C = g.shape[-1]
     R = g.numel() // C
     rows = part_rows((R + 63) // 64)
     part = torch.empty((rows, 2, C), dtype=torch.float32, device=g.device)
     writes = act != ACT_NONE or gate is not None or dpool is not None
+    if not writes:
+        out = g
+    elif out is None:
+        out = torch.empty_like(g)
     _launch("bn_act_bwd_reduce", g.numel() * g.element_size() * (3 if writes else 2), lib().mia_bn_act_bwd_reduce,
-            _DT[g.dtype], _p(g), _p(y), R, C, _p(stats[0]), _p(stats[1]), _p(stats[2]),
-                                _p(stats[3]), act, _p(gate), _p(dpool), rows_per_img, _p(part), rows, _stream())
-    return part
+            _DT[g.dtype], _p(g), _p(out) if writes else None, _p(y), R, C, _p(stats[0]), _p(stats[1]), _p(stats[2]),
+            _p(stats[3]), act, _p(gate), _p(dpool), rows_per_img, _p(part), rows, _stream())
+    return out, part
 
 
 def affine2(x, a, d, *, y=None, b=None, res=None, act=ACT_NONE, out=None):
@@ -553,9 +619,9 @@ class StemFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         col, y0, st, gamma = ctx.saved_tensors
-        g = dout.contiguous().view(y0.shape)   # updated in place: the incoming gradient has no other reader
         M = y0.shape[0]
-        part = bn_act_bwd_reduce(g, y0, st, ACT_SILU)
+        # into a fresh tensor: the incoming gradient belongs to autograd (a hook or retain_grad() may hold it)
+        g, part = bn_act_bwd_reduce(dout.contiguous().view(y0.shape), y0, st, ACT_SILU)
         coef = bn_finalize_bwd(part, M, gamma, st, ctx.training)
         affine2(g, coef[2], coef[4], y=y0, b=coef[3], out=g)
         dw = gemm_tn(g, col)  # [40, 32]
@@ -612,12 +678,21 @@ class MBConvFn(torch.autograd.Function):
         # casts made once per step: the transposed copies serve the data-gradient GEMMs of the backward
         ctx.wexpT, ctx.wprojT, ctx.weT = wexpT, wprojT, weT
         ctx.wexp = wexp if (cfg.kind == "ir" and need_bwd) else None
+        ctx.side_use = Side.Use((w_exp, w_dw, w_proj, w_ser, w_see)) if need_bwd else None
         ctx.save_for_backward(x, y1, st1, y2, st2, y3, st3, pooled, hpre, gate, w_exp, g1, w_dw, g2, w_ser, w_see,
                               w_proj, g3)
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        try:
+            return MBConvFn._backward(ctx, dout)
+        finally:
+            if ctx.side_use is not None:
+                ctx.side_use.release()
+
+    @staticmethod
+    def _backward(ctx, dout):
         (x, y1, st1, y2, st2, y3, st3, pooled, hpre, gate, w_exp, g1, w_dw, g2, w_ser, w_see, w_proj,
          g3) = ctx.saved_tensors
         cfg, training = ctx.cfg, ctx.training
@@ -629,12 +704,13 @@ class MBConvFn(torch.autograd.Function):
         dt = x.dtype
         k, s = cfg.k, cfg.s
         # ---- bn3 (no activation) ----
-        part = bn_act_bwd_reduce(dout, y3, st3, ACT_NONE)
+        _, part = bn_act_bwd_reduce(dout, y3, st3, ACT_NONE)
         c3 = bn_finalize_bwd(part, M2, g3, st3, training)
         dy3 = affine2(dout, c3[2], c3[4], y=y3, b=c3[3]).view(M2, Co)
         # ---- projection: weight and data gradients ----
-        wparams = (w_exp, w_dw, w_proj)
         work = M2 * Cm
+        # one answer for the whole block: none of these parameters changes state while this backward runs
+        wparams = work >= Side.MIN_WORK and Side.usable((w_exp, w_dw, w_proj, w_ser, w_see))
         with side_scope(x.device, wparams, (dy3, y2, st2, gate), work):
             dwproj = gemm_tn(dy3, y2.view(M2, Cm), pscale=st2[0], pshift=st2[1], pro_act=ACT_SILU, gate=gate,
                              rows_per_img=OH * OW)
@@ -644,7 +720,7 @@ class MBConvFn(torch.autograd.Function):
         sums = se_bwd_sums(y2, dz, st2)
         wr, weT = _w2d(w_ser), ctx.weT
         dpool, dpre2, dpre1 = se_gate_bwd(sums[0], OH * OW, wr, weT, gate, hpre, pooled)
-        with side_scope(x.device, wparams + (w_ser, w_see), (dpre2, dpre1, pooled, hpre), work):
+        with side_scope(x.device, wparams, (dpre2, dpre1, pooled, hpre), work):
             dwr, dbr, dwe, dbe = se_param_grad(dpre2, dpre1, pooled, hpre)
         # ---- bn after depthwise (+SiLU): its reductions come from the same per-image sums ----
         c2 = bn_finalize_bwd(se_bn_combine(sums, gate, dpool), M2, g2, st2, training)

@@ -9,7 +9,7 @@ import math
 import torch
 
 from ._lib import lib
-from .ops import Side, _stream
+from .ops import Side, WeightEpoch, _stream
 
 
 class AdamW(torch.optim.Optimizer):
@@ -78,6 +78,7 @@ class AdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         Side.sync()     # weight gradients still running on the side stream are ordered before the update
+        WeightEpoch.bump()      # the kernel rewrites the parameters through their raw pointers
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:

@@ -49,12 +49,12 @@ def zero_slice_filter(vol: torch.Tensor):
         raise TypeError(f"unsupported volume dtype {vol.dtype}")
     dev = vol.device
     flags = torch.empty((N,), dtype=torch.int32, device=dev)
-    keep = torch.empty((N,), dtype=torch.uint8, device=dev)
+    keep = torch.empty((N,), dtype=torch.bool, device=dev)      # one byte per slice, written as 0 / 1
     idx = torch.empty((N,), dtype=torch.int32, device=dev)
     count = torch.empty((1,), dtype=torch.int32, device=dev)
     lib().mia_zero_slice_filter(_p(vol), esz, 1 if is_float else 0, N, elems, _p(flags), _p(keep), _p(idx), _p(count),
                                 _stream())
-    return keep.bool(), idx, count
+    return keep, idx, count
 
 
 def gather_slices(vol: torch.Tensor, idx: torch.Tensor, count: torch.Tensor) -> torch.Tensor:

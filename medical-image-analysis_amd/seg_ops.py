@@ -73,16 +73,15 @@ class DecoderBlockFn(torch.autograd.Function):
         B, H, W, Cin, Co = ctx.shape
         M = B * H * W
         training = ctx.training
-        # bn2 + ReLU backward (the reduce pass writes the masked gradient in place, so work on a copy)
-        g = dout.contiguous().view(M, Co).clone()
-        part = ops.bn_act_bwd_reduce(g, y2, st2, ACT_RELU)
+        # bn2 + ReLU backward (the masked gradient goes to a fresh tensor: the incoming one is autograd's)
+        g, part = ops.bn_act_bwd_reduce(dout.contiguous().view(M, Co), y2, st2, ACT_RELU)
         c2 = ops.bn_finalize_bwd(part, M, g2, st2, training)
         dy2 = ops.affine2(g, c2[2], c2[4], y=y2, b=c2[3], out=g)
         dw2 = ops.gemm_tn(dy2, col2)
         dcol2, _ = ops.gemm_nt(dy2, ctx.w2mT)
         ga = col2im3x3(dcol2, (B, H, W, Co)).view(M, Co)
         # Dropout2d mask, ReLU and bn1 backward
-        part = ops.bn_act_bwd_reduce(ga, y1, st1, ACT_RELU, gate=mask, rows_per_img=H * W)
+        ga, part = ops.bn_act_bwd_reduce(ga, y1, st1, ACT_RELU, gate=mask, rows_per_img=H * W, out=ga)
         c1 = ops.bn_finalize_bwd(part, M, g1, st1, training)
         dy1 = ops.affine2(ga, c1[2], c1[4], y=y1, b=c1[3], out=ga)
         dw1 = ops.gemm_tn(dy1, col1)

@@ -214,9 +214,12 @@ class EfficientNetB3Features(nn.Module):
         handed out before (same addresses), so a captured HIP graph that reads them follows weight updates."""
         cached = _FOLDED.get(self)
         tens = cached[2] if cached is not None else self._fold_tensors()
-        # in-place writes bump the version counters; module.to()/cuda() replace the storages and come through _apply
+        # in-place writes by torch bump the version counters; this library's own kernels (AdamW, train-mode BatchNorm
+        # finalize, graph replays of a training step) write through raw pointers and bump ops.WeightEpoch instead;
+        # module.to()/cuda() replace the storages and come through _apply
         try:
-            key = (self.compute_dtype, tuple([t._version for t in tens]), tens[0].data_ptr(), tens[-1].data_ptr())
+            key = (self.compute_dtype, tuple([t._version for t in tens]), tens[0].data_ptr(), tens[-1].data_ptr(),
+                   ops.WeightEpoch.n)
         except RuntimeError:     # inference tensors keep no version counter: nothing to compare, fold again
             return self._build_folded()
         if cached is not None and cached[0] == key:

@@ -52,6 +52,12 @@ for k, d in out.items():
     n = d.get("FETCH_SIZE", d.get("WRITE_SIZE"))[0]
     fam[name][0] += n
     fam[name][1] += d.get("FETCH_SIZE", (0, 0))[1] + d.get("WRITE_SIZE", (0, 0))[1]
-json.dump({"unit_bytes_per_count": unit, "families": {k: {"launches_per_step": v[0], "hbm_bytes_per_step": v[1],
+import importlib.util, os
+_spec = importlib.util.spec_from_file_location("mia_build", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..",
+                                                                       "medical-image-analysis_amd", "build.py"))
+_build = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_build)        # a plain module: no torch, no GPU
+kernel_tree_hash = _build.kernel_tree_hash
+json.dump({"tree": kernel_tree_hash(), "unit_bytes_per_count": unit, "families": {k: {"launches_per_step": v[0], "hbm_bytes_per_step": v[1],
            "hbm_bytes_per_launch": v[1] / max(v[0], 1)} for k, v in fam.items()}},
           open(f"{root}/traffic_summary.json", "w"), indent=1)

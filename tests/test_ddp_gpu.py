@@ -29,7 +29,9 @@ def _worker(port, q):
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         import mia_amd  # noqa: F401
+        from mia_amd import ops
         from mia_amd.ddp import GradReducer
+        ops.Side.MIN_WORK = 0       # every block forks its weight gradients: the two-stream path is what runs here
         from mia_amd.head_ops import CrossEntropyLoss
         from mia_amd.optim import AdamW
         from mia_amd.src.model import FoundationModel
@@ -47,9 +49,14 @@ def _worker(port, q):
         model = make()
         seen = {}
         names = {id(p): n for n, p in model.named_parameters()}
-        # registered BEFORE the reducer's hooks: sees the gradient exactly as autograd left it
-        taps = [p.register_post_accumulate_grad_hook(lambda p: seen.__setitem__(names[id(p)], p.grad.clone()))
-                for p in model.parameters()]
+        # registered BEFORE the reducer's hooks: sees the gradient exactly as autograd left it. The gradient may still
+        # be in flight on the weight-gradient stream, so the tap joins the streams before it reads (and says so:
+        # parameters with hooks that do not are kept off the second stream)
+        def tap(p):
+            ops.Side.sync()
+            seen[names[id(p)]] = p.grad.clone()
+        tap._mia_side_aware = True
+        taps = [p.register_post_accumulate_grad_hook(tap) for p in model.parameters()]
         red = GradReducer(model.parameters(), bucket_bytes=4 << 20, always_exchange=True)
         red.broadcast_parameters(model)
         assert red.exchange and len(red.buckets) >= 8
@@ -67,6 +74,48 @@ def _worker(port, q):
             n += p.numel()
         for t in taps:
             t.remove()
+        red.remove()
+
+        # ---- the exchange does not stall the data-gradient chain. The weight-gradient stream is held busy by a spin
+        # kernel queued before backward; every bucket is packed and all-reduced behind it. The caller's stream must
+        # nevertheless run through the whole backward pass: an event recorded on it when the LAST gradient of the
+        # pass lands (the stem convolution's) completes while the spin kernel is still running.
+        import time
+        dev = torch.device("cuda", 0)
+        m2 = make()
+        red2 = GradReducer(m2.parameters(), bucket_bytes=4 << 20, always_exchange=True)
+        red2.zero_grad()
+        loss2 = crit(m2(x, "classification", "synthetic"), y)
+        side = ops.Side(dev).side
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        torch.cuda._sleep(2_000_000)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_per_cycle = max(e0.elapsed_time(e1), 1e-3) / 2_000_000
+        spin = int(min(1500.0 / ms_per_cycle, 2e10))
+        side_done, main_done = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(spin)
+            side_done.record()
+
+        def last_tap(p):
+            main_done.record()          # on the caller's stream, after everything its backward queued there
+        last_tap._mia_side_aware = True
+        h = m2.backbone.conv_stem.weight.register_post_accumulate_grad_hook(last_tap)
+        t0 = time.perf_counter()
+        loss2.backward()
+        assert len(red2._works) == len(red2.buckets)
+        while not main_done.query() and time.perf_counter() - t0 < 1.2:
+            time.sleep(0.005)
+        assert main_done.query(), "the caller's stream did not get through backward while the side stream was busy"
+        assert not side_done.query(), "the spin kernel ended early: the check proved nothing"
+        red2.finish()
+        torch.cuda.synchronize()
+        h.remove()
+        for name, p in m2.named_parameters():
+            assert torch.equal(p.grad, seen[name]), f"{name}: gradient changed when the exchange ran on the side stream"
+        red2.remove()
 
         # three optimizer steps with and without the exchange follow the same trajectory
         def run(with_reducer):

@@ -63,12 +63,14 @@ def _cls_model(dtype, dropout):
     return model
 
 
+@pytest.mark.parametrize("fork", [True, False])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_graphed_train_step_follows_eager(dtype):
+def test_graphed_train_step_follows_eager(dtype, fork):
     """Without dropout a graphed run and an eager run from the same start are the same computation: every kernel of
     the step adds its partial results in a fixed order (no float atomics), the replayed AdamW reads the same
     step-dependent factors the eager launch forms, so losses, parameters, optimizer state and BatchNorm buffers agree
-    BIT FOR BIT after 5 steps in either precision, including a learning-rate change made between steps."""
+    BIT FOR BIT after 5 steps in either precision, including a learning-rate change made between steps. fork=True:
+    the graph carries the weight-gradient branch on a second stream (fork and join captured), as the eager step does."""
     eager = _cls_model(dtype, 0.0)
     graphed = copy.deepcopy(eager)
     start = [p.detach().clone() for p in graphed.parameters()]
@@ -78,7 +80,8 @@ def test_graphed_train_step_follows_eager(dtype):
     g = torch.Generator(device="cuda").manual_seed(1)
     batches = [(torch.randn(4, 3, 96, 96, device="cuda", generator=g),
                 torch.randint(0, 4, (4,), device="cuda", generator=g)) for _ in range(5)]
-    step = GraphedTrainStep(graphed, "classification", "d", crit, opt_g, *batches[0])
+    step = GraphedTrainStep(graphed, "classification", "d", crit, opt_g, *batches[0], fork=fork)
+    assert step.fork == fork
     # construction leaves training where it was
     for p, s0 in zip(graphed.parameters(), start):
         assert torch.equal(p, s0)

@@ -247,8 +247,9 @@ def test_bn_silu_gate_backward_chain(dtype, C, hw, B):
     loss.backward()
     st = torch.stack([gamma * rstd.detach(), beta - mean.detach() * gamma * rstd.detach(), mean.detach(),
                       rstd.detach()]).contiguous()
-    g = dz.clone()
-    part = ops.bn_act_bwd_reduce(g, y, st, ops.ACT_SILU, gate=gate, dpool=dpool, rows_per_img=hw)
+    dz0 = dz.clone()
+    g, part = ops.bn_act_bwd_reduce(dz, y, st, ops.ACT_SILU, gate=gate, dpool=dpool, rows_per_img=hw)
+    assert torch.equal(dz, dz0) and g.data_ptr() != dz.data_ptr()      # the incoming gradient is left alone
     coef = ops.bn_finalize_bwd(part, R, gamma, st, True)
     dy = ops.affine2(g, coef[2], coef[4], y=y, b=coef[3])
     assert relerr(dy.float(), yr.grad) < tol(dtype, 5e-5, 3e-2)

@@ -103,3 +103,29 @@ def test_idempotent_and_sorted_at_full_size():
     keep2, idx2, count2 = PP.zero_slice_filter(packed.contiguous())
     assert int(count2.item()) == k and bool(keep2.all())          # filtering a filtered volume keeps everything
     assert int(keep.sum().item()) == k
+
+
+def test_zero_slice_filter_many_calls_and_large_slices():
+    """Slices of up to 1 MiB take the one-launch path (a workgroup per slice, the last one to finish compacts; its
+    arrival counters come from a pool of 64 that each call leaves at zero): 150 calls in a row with changing slice
+    counts cycle through every counter more than twice. Larger slices take the split path (several workgroups per
+    slice). Both bit-exact against the numpy specification."""
+    rng = np.random.default_rng(5)
+    for call in range(150):
+        n = int(rng.integers(1, 40))
+        vol = rng.integers(0, 2, (n, 64, 64)).astype(np.uint8) * (rng.random((n, 1, 1)) < 0.6)
+        keep_ref, idx_ref = R.zero_slice_filter(vol)
+        keep, idx, count = PP.zero_slice_filter(torch.from_numpy(vol).cuda())
+        k = int(count.item())
+        assert k == idx_ref.size, call
+        np.testing.assert_array_equal(keep.cpu().numpy(), keep_ref)
+        np.testing.assert_array_equal(idx.cpu().numpy()[:k], idx_ref)
+    big = np.zeros((7, 1024, 640), np.int16)        # 1.25 MiB per slice
+    big[1, 1023, 639] = 1
+    big[2, 0, 0] = -1
+    big[5, 512, 17] = 3
+    keep_ref, idx_ref = R.zero_slice_filter(big)
+    keep, idx, count = PP.zero_slice_filter(torch.from_numpy(big).cuda())
+    assert int(count.item()) == 3
+    np.testing.assert_array_equal(keep.cpu().numpy(), keep_ref)
+    np.testing.assert_array_equal(idx.cpu().numpy()[:3], idx_ref)

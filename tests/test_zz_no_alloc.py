@@ -50,6 +50,23 @@ def test_static_scratch_matches_workspace_entry_point():
         np.testing.assert_array_equal(idx_b, idx_ref)
 
 
+def test_static_scratch_large_slices_second_call_smaller():
+    """Slices above 1 MiB take the path whose flag words are OR-ed into the scratch array by several workgroups per
+    slice (and cleared first): again two calls in a row, the second on fewer slices, against the workspace entry."""
+    lib = mia_amd.lib()
+    for n, seed in ((11, 31), (4, 32)):
+        vol = _volume(n, seed, h=1024, w=640)
+        tv = torch.from_numpy(vol).cuda()
+        keep_a, idx_a, k_a = _run(lib.mia_zero_slice_filter, tv, True)
+        keep_b, idx_b, k_b = _run(lib.mia_zero_slice_filter_static, tv, False)
+        assert k_a == k_b
+        np.testing.assert_array_equal(keep_b, keep_a)
+        np.testing.assert_array_equal(idx_b, idx_a)
+        keep_ref, idx_ref = R.zero_slice_filter(vol)
+        np.testing.assert_array_equal(keep_b.astype(bool), keep_ref)
+        np.testing.assert_array_equal(idx_b, idx_ref)
+
+
 def test_static_scratch_rejects_oversize():
     lib = mia_amd.lib()
     tv = torch.zeros((4, 16), dtype=torch.uint8, device="cuda")
