@@ -42,18 +42,6 @@ long long mia_launch_count(void);
 int mia_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* D, int M,
                 int N, int K, const float* pscale, const float* pshift, int pro_act, const float* gate,
                 int rows_per_img, const float* bias, int epi_act, float* stats, int part_rows, void* stream);
-/* The same product followed, in the same launch, by the train-mode BatchNorm finalize of its output (a 1x1
- * convolution and the statistics half of the BatchNormAct2d behind it: timm conv_pw + bn1 / conv_pwl + bn3 reached
- * through src/model.py:283-288): mia_gemm_nt with stats, then what mia_bn_finalize_fwd(training=1) computes from the
- * slab -- scale, shift, mean, rstd [N] and the running-statistics update -- done by the last workgroup of each column
- * tile to finish. tickets: at least N/32 + 1 words of device memory that are ZERO on entry and are left zero (a ring
- * of them can be handed to launch after launch on one stream). stats and part_rows as in mia_gemm_nt (required). */
-int mia_gemm_nt_bn(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
-                   const float* pscale, const float* pshift, int pro_act, const float* gate, int rows_per_img,
-                   float* stats, int part_rows, double count, const float* gamma, const float* beta,
-                   float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
-                   const float* conv_bias, float* scale, float* shift, float* mean, float* rstd, unsigned* tickets,
-                   void* stream);
 
 /* Weight gradient (autograd of the ops above, train.py:370): O[N,K] (fp32, leading dim ldo) = G[M,N]^T . pro(X)[M,K].
  * The reduction over M is split across workgroups. With a workspace (ws != NULL, at least

@@ -10,7 +10,6 @@
 //
 // Storage type T is float (exact-f32 MFMA 16x16x4) or bf16 (MFMA 16x16x32); accumulation is fp32.
 #include "common.h"
-#include "bnfin.h"
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -172,7 +171,6 @@ struct GemmNTParams {
     int alias_cs;   // 1: the C staging rows reuse the operand stage (one more barrier per tile, less LDS)
     int dump_off;   // byte offset of the per-thread 16-byte dump slots
     int pro_off;    // byte offset of the prologue vectors (scale[K], shift[K]) staged once per workgroup (PRO == 2)
-    BnFinFwd fin;   // fin.tickets != null: the column tile's last workgroup also finalizes the BatchNorm (bnfin.h)
 };
 
 // Guarded 16-byte loads through a buffer descriptor: an offset at or beyond the descriptor's size returns zeros,
@@ -540,18 +538,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
                 s += sred[(w * BN + tid) * 2 + 0];
                 q += sred[(w * BN + tid) * 2 + 1];
             }
-            // agent scope: with the fused finalize another workgroup (possibly on another XCD) reads this row
-            store_agent(stats + ((size_t)rowslot * 2 + 0) * N + n0 + tid, s);
-            store_agent(stats + ((size_t)rowslot * 2 + 1) * N + n0 + tid, q);
-        }
-        if (p.fin.tickets) {
-            // the workgroups of this column tile: one per row slot. The last one reduces the tile's columns.
-            if (mia_last_arriver(p.fin.tickets + n0 / BN, (unsigned)p.row_slots, reinterpret_cast<int*>(smem))) {
-                const int ncols = N - n0 < BN ? N - n0 : BN;
-                double* sums;
-                mia_slab_colsum(stats, p.row_slots, N, n0, ncols, smem, sums);
-                mia_bn_fin_fwd_cols(p.fin, sums, n0, ncols, n0 == 0);
-            }
+            stats[((size_t)rowslot * 2 + 0) * N + n0 + tid] = s;
+            stats[((size_t)rowslot * 2 + 1) * N + n0 + tid] = q;
         }
     }
 }
@@ -593,7 +581,6 @@ static int launch_nt_(const GemmNTParams& p, int part_rows, hipStream_t stream) 
     q.alias_cs = (stage_bytes + strip_bytes) * 3 > 160 * 1024 ? 1 : 0;
     int lds = q.alias_cs ? (stage_bytes > strip_bytes ? stage_bytes : strip_bytes) : stage_bytes + strip_bytes;
     if (lds < red_bytes) lds = red_bytes;
-    if (p.fin.tickets && lds < MIA_FIN_LDS_BYTES) lds = MIA_FIN_LDS_BYTES;
     lds = (lds + 15) & ~15;
     q.dump_off = lds;
     lds += 256 * 16;
@@ -648,10 +635,10 @@ static int dispatch_nt(const GemmNTParams& p, int part_rows, hipStream_t stream)
     }
 }
 
-static int gemm_nt_impl(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* D,
-                        int M, int N, int K, const float* pscale, const float* pshift, int pro_act,
-                        const float* gate, int rows_per_img, const float* bias, int epi_act, float* stats,
-                        int part_rows, const BnFinFwd* fin, void* stream) {
+extern "C" int mia_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* D,
+                           int M, int N, int K, const float* pscale, const float* pshift, int pro_act,
+                           const float* gate, int rows_per_img, const float* bias, int epi_act, float* stats,
+                           int part_rows, void* stream) {
     const int vec = dtype == MIA_BF16 ? 8 : 4;
     MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "mia_gemm_nt: bad dtype %d", dtype);
     MIA_CHECK_ARG(A && B && C, "mia_gemm_nt: null operand");
@@ -673,38 +660,11 @@ static int gemm_nt_impl(int dtype, const void* A, int lda, const void* B, int ld
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.pscale = pscale; p.pshift = pshift; p.gate = gate; p.rows_per_img = rows_per_img > 0 ? rows_per_img : 1;
     p.pro_act = pro_act; p.bias = bias; p.epi_act = epi_act; p.stats = stats;
-    if (fin) p.fin = *fin;
-    else p.fin.tickets = nullptr;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIA_BF16) dispatch_nt<bf16_t>(p, part_rows, s);
     else dispatch_nt<float>(p, part_rows, s);
     MIA_CHECK_LAUNCH("mia_gemm_nt");
     return 0;
-}
-
-extern "C" int mia_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* D,
-                           int M, int N, int K, const float* pscale, const float* pshift, int pro_act,
-                           const float* gate, int rows_per_img, const float* bias, int epi_act, float* stats,
-                           int part_rows, void* stream) {
-    return gemm_nt_impl(dtype, A, lda, B, ldb, C, ldc, D, M, N, K, pscale, pshift, pro_act, gate, rows_per_img, bias,
-                        epi_act, stats, part_rows, nullptr, stream);
-}
-
-extern "C" int mia_gemm_nt_bn(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
-                              int K, const float* pscale, const float* pshift, int pro_act, const float* gate,
-                              int rows_per_img, float* stats, int part_rows, double count, const float* gamma,
-                              const float* beta, float* running_mean, float* running_var,
-                              long long* num_batches_tracked, float momentum, float eps, const float* conv_bias,
-                              float* scale, float* shift, float* mean, float* rstd, unsigned* tickets, void* stream) {
-    MIA_CHECK_ARG(stats && tickets && scale && shift && mean && rstd && count > 0,
-                  "mia_gemm_nt_bn: stats, tickets and the four output vectors are required");
-    MIA_CHECK_ARG(!(running_mean == nullptr) == !(running_var == nullptr), "mia_gemm_nt_bn: running mean/var come together");
-    BnFinFwd fin;
-    fin.tickets = tickets; fin.gamma = gamma; fin.beta = beta; fin.rmean = running_mean; fin.rvar = running_var;
-    fin.nbt = num_batches_tracked; fin.momentum = momentum; fin.eps = eps; fin.count = count; fin.conv_bias = conv_bias;
-    fin.scale = scale; fin.shift = shift; fin.mean = mean; fin.rstd = rstd;
-    return gemm_nt_impl(dtype, A, lda, B, ldb, C, ldc, nullptr, M, N, K, pscale, pshift, pro_act, gate, rows_per_img,
-                        nullptr, MIA_ACT_NONE, stats, part_rows, &fin, stream);
 }
 
 // ================================================================================================

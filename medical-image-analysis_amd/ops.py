@@ -68,28 +68,6 @@ def _require_cuda(t: torch.Tensor):
         raise RuntimeError("mia_amd kernels need tensors on an MI355X device; there is no CPU path")
 
 
-class Tickets:
-    """Arrival counters for the kernels that fuse a reduction across their workgroups into the producing launch
-    (mia_gemm_nt_bn, mia_dwconv_fwd_bn, ...): device words that are zero when a launch starts and that the launch
-    leaves zero. One ring per (device, stream): launches on one stream run in order, so by the time the ring wraps
-    the launch that used a slot before has finished; kernels on different streams never share a slot."""
-    SIZE = 1 << 16
-    enabled = True      # A/B switch: off = separate finalize launches
-    _rings = {}
-
-    @classmethod
-    def take(cls, device, n: int) -> int:
-        key = (device.index, _stream())
-        ent = cls._rings.get(key)
-        if ent is None:
-            ent = cls._rings[key] = [torch.zeros((cls.SIZE,), dtype=torch.int32, device=device), 0]
-        if ent[1] + n > cls.SIZE:
-            ent[1] = 0
-        ptr = ent[0].data_ptr() + 4 * ent[1]
-        ent[1] += n
-        return ptr
-
-
 def part_rows(work_items: int) -> int:
     return max(1, min(MAX_PART, int(work_items)))
 
@@ -275,36 +253,18 @@ def _launch(family, nbytes, fn, *args):
 # primitive wrappers
 # ------------------------------------------------------------------------------------------------
 def gemm_nt(a2d, b, out2d=None, *, pscale=None, pshift=None, pro_act=ACT_NONE, gate=None, rows_per_img=0,
-            bias=None, epi_act=ACT_NONE, add=None, stats_rows=0, ldc=None, bn=None):
-    """out[M,N] = pro(a)[M,K] @ b[N,K]^T ...; returns (out, part or None).
-    bn (a BNState in training mode, with stats_rows > 0): the launch also finalizes that BatchNorm over the M rows
-    (mia_gemm_nt_bn); returns (out, st) with st rows scale, shift, mean, rstd as bn_finalize_fwd gives them."""
+            bias=None, epi_act=ACT_NONE, add=None, stats_rows=0, ldc=None):
+    """out[M,N] = pro(a)[M,K] @ b[N,K]^T ...; returns (out, part or None)."""
     _require_cuda(a2d)
     M, K = a2d.shape
     N = b.shape[0]
     assert b.shape[1] == K and a2d.dtype == b.dtype, (a2d.shape, b.shape, a2d.dtype, b.dtype)
-    if bn is not None and not (stats_rows and bn.training and Tickets.enabled):
-        # eval-mode statistics, or the fused finalize switched off: the product, then the finalize launch
-        out2d, part = gemm_nt(a2d, b, out2d, pscale=pscale, pshift=pshift, pro_act=pro_act, gate=gate,
-                              rows_per_img=rows_per_img, stats_rows=stats_rows if bn.training else 0, ldc=ldc)
-        return out2d, bn_finalize_fwd(part, M, bn)
     if out2d is None:
         out2d = torch.empty((M, N), dtype=a2d.dtype, device=a2d.device)
     part = None
     if stats_rows:
         part = torch.empty((stats_rows, 2, N), dtype=torch.float32, device=a2d.device)
     esz = a2d.element_size()
-    if bn is not None:
-        assert bias is None and add is None and epi_act == ACT_NONE
-        st = torch.empty((4, N), dtype=torch.float32, device=a2d.device)
-        if bn.running_mean is not None:
-            WeightEpoch.bump()
-        _launch("gemm_nt", (M * K + N * K + M * N) * esz, lib().mia_gemm_nt_bn, _DT[a2d.dtype], _p(a2d), a2d.stride(0),
-                _p(b), b.stride(0), _p(out2d), ldc if ldc is not None else out2d.stride(0), M, N, K, _p(pscale),
-                _p(pshift), pro_act, _p(gate), rows_per_img, _p(part), stats_rows, float(M), _p(bn.weight), _p(bn.bias),
-                _p(bn.running_mean), _p(bn.running_var), _p(bn.nbt), float(bn.momentum), float(bn.eps), None,
-                _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), Tickets.take(a2d.device, N // 32 + 1), _stream())
-        return out2d, st
     _launch("gemm_nt", (M * K + N * K + M * N * (2 if add is not None else 1)) * esz, lib().mia_gemm_nt, _DT[a2d.dtype], _p(a2d), a2d.stride(0), _p(b), b.stride(0), _p(out2d),
                       ldc if ldc is not None else out2d.stride(0), _p(add), M, N, K, _p(pscale), _p(pshift), pro_act,
                       _p(gate), rows_per_img, _p(bias), epi_act, _p(part), stats_rows, _stream())
@@ -649,7 +609,8 @@ class StemFn(torch.autograd.Function):
         M = B * OH * OW
         bn = cfg.bn
         rows = part_rows((M + 255) // 256) if bn.training else 0
-        y0, st = gemm_nt(col, wp, stats_rows=rows, bn=bn)
+        y0, part = gemm_nt(col, wp, stats_rows=rows)
+        st = bn_finalize_fwd(part, M, bn)
         out = affine2(y0, st[0], st[1], act=ACT_SILU).view(B, OH, OW, -1)
         ctx.cfg, ctx.training = cfg, bn.training
         ctx.save_for_backward(col, y0, st, gamma)
@@ -684,8 +645,8 @@ class MBConvFn(torch.autograd.Function):
             M = B * H * W
             # [Cm, Cin] and, for the backward, [Cin, Cm]; cast by the trunk in one launch for all blocks when it can
             wexp, wexpT = cfg.pre["exp"] if cfg.pre else cast_weight(_w2d(w_exp), dt, want_t=need_bwd)
-            y1, st1 = gemm_nt(x.view(M, Cin), wexp, stats_rows=part_rows((M + 63) // 64) if training else 0,
-                              bn=cfg.bn_exp)
+            y1, part = gemm_nt(x.view(M, Cin), wexp, stats_rows=part_rows((M + 63) // 64) if training else 0)
+            st1 = bn_finalize_fwd(part, M, cfg.bn_exp)
             y1 = y1.view(B, H, W, -1)
             dw_in, dw_sc, dw_sh = y1, st1[0], st1[1]
         else:
@@ -707,9 +668,9 @@ class MBConvFn(torch.autograd.Function):
         pooled, hpre, gate = se_gate_fwd(pool_part, OH * OW, wr, b_ser.detach(), weT, b_see.detach())
         # ---- projection ----
         wproj, wprojT = cfg.pre["proj"] if cfg.pre else cast_weight(_w2d(w_proj), dt, want_t=need_bwd)   # [Co, Cm], [Cm, Co]
-        y3, st3 = gemm_nt(y2.view(M2, Cm), wproj, pscale=st2[0], pshift=st2[1], pro_act=ACT_SILU, gate=gate,
-                          rows_per_img=OH * OW, stats_rows=part_rows((M2 + 63) // 64) if training else 0,
-                          bn=cfg.bn_proj)
+        y3, part = gemm_nt(y2.view(M2, Cm), wproj, pscale=st2[0], pshift=st2[1], pro_act=ACT_SILU, gate=gate,
+                           rows_per_img=OH * OW, stats_rows=part_rows((M2 + 63) // 64) if training else 0)
+        st3 = bn_finalize_fwd(part, M2, cfg.bn_proj)
         Co = y3.shape[1]
         y3 = y3.view(B, OH, OW, Co)
         out = affine2(y3, st3[0], st3[1], res=x if cfg.has_skip else None)

@@ -34,49 +34,6 @@ def test_library_targets_this_device():
     mia_amd.lib().mia_check_device()
 
 
-
-class _BN:
-    """Stand-in for ops.BNState with fresh buffers."""
-
-    def __init__(self, C, seed, training=True):
-        self.weight, self.bias = rnd(C, seed=seed).abs() + 0.5, rnd(C, seed=seed + 1)
-        self.running_mean, self.running_var = rnd(C, seed=seed + 2), rnd(C, seed=seed + 3).abs() + 0.5
-        self.nbt = torch.zeros((), dtype=torch.long, device=DEV)
-        self.momentum, self.eps, self.training = 0.1, 1e-5, training
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K,rows", [(12800, 232, 1392, 200), (12800, 1392, 232, 200), (5000, 144, 24, 79),
-                                        (300, 24, 40, 5), (46208, 136, 816, 512), (900, 40, 32, 512), (64, 384, 64, 1)])
-def test_gemm_nt_fused_bn_finalize(dtype, M, N, K, rows):
-    """mia_gemm_nt_bn (the BatchNorm finalize done by the last workgroup of each column tile) against the two-launch
-    form mia_gemm_nt + mia_bn_finalize_fwd: same output tensor bit for bit, the four vectors and the running
-    statistics to 1e-6 (both sum the same partial rows in double, in a different order), num_batches_tracked bumped
-    once; three calls in a row reuse the ticket ring."""
-    a = rnd(M, K, seed=1, dtype=dtype)
-    b = rnd(N, K, seed=2, scale=K ** -0.5, dtype=dtype)
-    hw = 100
-    gate = rnd((M + hw - 1) // hw, K, seed=3).sigmoid() if K % 8 == 0 and N <= 384 else None
-    psc, psh = (rnd(K, seed=4).abs() + 0.5, rnd(K, seed=5)) if gate is not None else (None, None)
-    kw = dict(pscale=psc, pshift=psh, pro_act=ops.ACT_SILU if gate is not None else ops.ACT_NONE, gate=gate,
-              rows_per_img=hw if gate is not None else 0)
-    for it in range(3):
-        bn_a, bn_b = _BN(N, 10 + it), _BN(N, 10 + it)
-        ops.Tickets.enabled = False
-        try:
-            out_a, st_a = ops.gemm_nt(a, b, stats_rows=rows, bn=bn_a, **kw)
-        finally:
-            ops.Tickets.enabled = True
-        out_b, st_b = ops.gemm_nt(a, b, stats_rows=rows, bn=bn_b, **kw)
-        assert torch.equal(out_a, out_b)
-        assert relerr(st_b, st_a) < 1e-6
-        assert relerr(bn_b.running_mean, bn_a.running_mean) < 1e-6
-        assert relerr(bn_b.running_var, bn_a.running_var) < 1e-6
-        assert int(bn_a.nbt) == int(bn_b.nbt) == 1
-    ring = ops.Tickets._rings[(0, ops._stream())][0]
-    assert int(ring.abs().sum()) == 0, "a launch left a ticket counter non-zero"
-
-
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(300, 24, 40), (1000, 144, 24), (777, 32, 192), (513, 48, 288), (260, 136, 816),
