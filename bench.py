@@ -86,7 +86,8 @@ def main():
     ap.add_argument("--no-fork", action="store_true", help="A/B switch: weight gradients on the main stream instead of the side stream")
     ap.add_argument("--kernel-table", action="store_true", help="also print a per-family timing table to stderr")
     ap.add_argument("--graph", action="store_true",
-                    help="time HIP-graph replays of the step (single GPU; fork/join captured unless --no-fork)")
+                    help="time HIP-graph replays of the step (single GPU)")
+    ap.add_argument("--graph-fork", action="store_true", help="with --graph: capture the weight-gradient fork/join")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,7 +158,7 @@ def main():
             raise SystemExit("--graph is single-GPU: the gradient all-reduce is not captured")
         from mia_amd.graphs import GraphedTrainStep
         graphed = GraphedTrainStep(model, "classification", "synthetic", criterion, opt, xs[0], ys[0],
-                                   fork=not args.no_fork)
+                                   fork=args.graph_fork)
 
         def step():     # noqa: F811  (the same step, replayed)
             i = counter[0] % NBATCH

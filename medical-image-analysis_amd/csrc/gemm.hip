@@ -689,30 +689,7 @@ struct GemmTNParams {
     float* ws;      // [tiles][splits][slot], unused when splits == 1
     int splits;
     int slot;       // floats per slot = rows x cols of the largest tile
-    int tiles_n, tiles_k;
-    int xcd_map;    // 1: 1-D grid, the tiles of one split on one XCD (see tn_block)
 };
-
-// Workgroup -> (n tile, k tile, split). With the plain 3-D grid the tiles of one split get consecutive workgroup ids
-// and are dealt round-robin over the eight XCDs, so every XCD's L2 fetches the split's rows of BOTH operands although
-// each tile needs one column range of each. In the 1-D form workgroup ids b and b+8 share an XCD: the tiles of split
-// z all run on XCD z % 8, the operand rows of the split are fetched into that one L2 and the sibling tiles read them
-// there. Purely a speed choice: the partial tiles and their order of addition are the same either way.
-struct TnBlock { int bx, by, bz; bool valid; };
-__device__ __forceinline__ TnBlock tn_block(const GemmTNParams& p) {
-    TnBlock b;
-    if (!p.xcd_map) {
-        b.bx = blockIdx.x; b.by = blockIdx.y; b.bz = blockIdx.z; b.valid = true;
-        return b;
-    }
-    const int tiles = p.tiles_n * p.tiles_k;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    b.bz = (j / tiles) * 8 + xcd;
-    const int t = j % tiles;
-    b.bx = t % p.tiles_n; b.by = t / p.tiles_n;
-    b.valid = b.bz < p.splits;
-    return b;
-}
 
 // Second kernel of the deterministic weight gradient: O tile = sum over the splits' partial tiles, in split order.
 // A workgroup owns 256/ZL float4 columns of one tile; its ZL "z-lanes" each add every ZL-th slot (strided, so all of
@@ -790,9 +767,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
     const T* __restrict__ X = reinterpret_cast<const T*>(p.X);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
-    const TnBlock blk = tn_block(p);
-    if (!blk.valid) return;
-    const int n0 = blk.bx * TN, k0 = blk.by * TK;
+    const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
     const int M = p.M, N = p.N, K = p.K;
     const bool has_pro = PRO && p.pscale != nullptr;
     const bool has_gate = PRO && p.gate != nullptr;
@@ -829,7 +804,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
         ssm[TK + tid] = in ? p.pshift[k0 + tid] : 0.f;
     }
 
-    const long long chunk_begin = (long long)blk.bz * p.chunks_per_split;
+    const long long chunk_begin = (long long)blockIdx.z * p.chunks_per_split;
     long long chunk_end = chunk_begin + p.chunks_per_split;
     const long long total_chunks = ((long long)M + BR - 1) / BR;
     if (chunk_end > total_chunks) chunk_end = total_chunks;
@@ -986,8 +961,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
     // ---- deterministic path: this split's partial tile to its slot (or straight to O when there is one split) ----
     const int nh = N - n0 < TN ? N - n0 : TN, kw = K - k0 < TK ? K - k0 : TK;   // valid extent of this tile
     const int S = p.splits;
-    const int tile = blk.by * p.tiles_n + blk.bx;
-    float* dst = S == 1 ? p.O + (size_t)n0 * p.ldo + k0 : p.ws + ((size_t)tile * S + blk.bz) * p.slot;
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+    float* dst = S == 1 ? p.O + (size_t)n0 * p.ldo + k0 : p.ws + ((size_t)tile * S + blockIdx.z) * p.slot;
     const int dld = S == 1 ? p.ldo : kw;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -1038,9 +1013,6 @@ static TnPlan tn_plan(int dtype, int M, int N, int K, bool pro) {
     if (splits < 1) splits = 1;
     if (splits > (chunks + min_chunks - 1) / min_chunks) splits = (chunks + min_chunks - 1) / min_chunks;
     if (splits < 1) splits = 1;
-    // several tiles per split: the splits are dealt over the eight XCDs (tn_block), so a multiple of eight keeps the
-    // XCDs evenly loaded
-    if (t.tiles > 1 && splits >= 12) splits = (splits + 4) / 8 * 8;
     t.chunks_per_split = (int)((chunks + splits - 1) / splits);
     t.splits = (int)((chunks + t.chunks_per_split - 1) / t.chunks_per_split);
     t.slot = (N < tn ? N : tn) * (K < tk ? K : tk);
@@ -1086,11 +1058,7 @@ extern "C" int mia_gemm_tn(int dtype, const void* G, int ldg, const void* X, int
     }
     const long long splits = t.splits;
     const TnShape sh = TN_SHAPES[t.shape];
-    p.tiles_n = cdiv(N, sh.tn); p.tiles_k = cdiv(K, sh.tk);
-    static const int xcd_env = getenv("MIA_TN_XCD") ? atoi(getenv("MIA_TN_XCD")) : 1;
-    p.xcd_map = (xcd_env && t.tiles > 1 && splits >= 8) ? 1 : 0;
-    dim3 grid(p.tiles_n, p.tiles_k, (unsigned)splits);
-    if (p.xcd_map) grid = dim3((unsigned)(cdiv(splits, 8) * 8 * t.tiles), 1, 1);
+    dim3 grid(cdiv(N, sh.tn), cdiv(K, sh.tk), (unsigned)splits);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define MIA_TN_GO(T_, TN_, TK_, WR_)                                                                             \
     do {                                                                                                         \

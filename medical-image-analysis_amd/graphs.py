@@ -70,16 +70,19 @@ class GraphedTrainStep:
     are drawn from torch's CPU generator state at every replay (reproducible under torch.manual_seed) but are not
     the same masks an eager step would draw. Single process only: gradients are not all-reduced inside the graph.
 
-    fork=True (default) captures the weight-gradient kernels on ops.Side's second stream, as the eager step runs them:
-    the fork and join events become edges of the graph, so a replay runs the two branches side by side. The capture
-    stream is a stream of this object's own, used for the warm-up steps as well, so the stream pair exists before the
-    capture begins. fork=False records everything on one stream."""
+    fork=True captures the weight-gradient kernels on ops.Side's second stream, as the eager step runs them: the fork
+    and join events become edges of the graph, so a replay may run the two branches side by side. The capture stream
+    is a stream of this object's own, used for the warm-up steps as well, so the stream pair exists before the
+    capture begins. fork=False (default) records everything on one stream. Measured on an MI355X at batch 128
+    (bench.py --graph): one stream 25.7 ms per step, forked 26.1 ms, eager two-stream launches 24.6 ms -- the graph
+    executor of this ROCm release gains nothing from the forked branches and pays for their join nodes, so the fork is
+    kept as a tested option (bit-identical results either way) and not made the default."""
 
     WORDS = 64           # device words: [0:2] seed offset (uint64), [4:] AdamW rows of 4 floats
     MAX_ROWS = (WORDS - 4) // 4
 
     def __init__(self, model, task: str, dataset_name: str, criterion, optimizer, example_input: torch.Tensor,
-                 example_target: torch.Tensor, warmup: int = 2, fork: bool = True):
+                 example_target: torch.Tensor, warmup: int = 2, fork: bool = False):
         from .optim import AdamW
         if not model.training:
             raise RuntimeError("GraphedTrainStep captures the train-mode step: call model.train() first")

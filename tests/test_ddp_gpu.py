@@ -76,43 +76,40 @@ def _worker(port, q):
             t.remove()
         red.remove()
 
-        # ---- the exchange does not stall the data-gradient chain. The weight-gradient stream is held busy by a spin
-        # kernel queued before backward; every bucket is packed and all-reduced behind it. The caller's stream must
-        # nevertheless run through the whole backward pass: an event recorded on it when the LAST gradient of the
-        # pass lands (the stem convolution's) completes while the spin kernel is still running.
-        import time
-        dev = torch.device("cuda", 0)
+        # ---- the exchange does not stall the data-gradient chain: during the backward pass the caller's stream is
+        # never made to wait for the weight-gradient stream because of a bucket. Every stream wait issued from Python
+        # while backward runs is recorded with the number of buckets launched so far; the caller's stream may wait
+        # for the side stream only once every bucket is out (the join at the end of the pass). (A timing check with a
+        # spin kernel parked on the side stream was tried first: two torch streams can share a hardware queue, where
+        # the spin kernel then holds up the caller's kernels as well, whatever the events say.)
         m2 = make()
         red2 = GradReducer(m2.parameters(), bucket_bytes=4 << 20, always_exchange=True)
         red2.zero_grad()
         loss2 = crit(m2(x, "classification", "synthetic"), y)
-        side = ops.Side(dev).side
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        torch.cuda._sleep(2_000_000)
-        e1.record()
-        torch.cuda.synchronize()
-        ms_per_cycle = max(e0.elapsed_time(e1), 1e-3) / 2_000_000
-        spin = int(min(1500.0 / ms_per_cycle, 2e10))
-        side_done, main_done = torch.cuda.Event(), torch.cuda.Event()
-        with torch.cuda.stream(side):
-            torch.cuda._sleep(spin)
-            side_done.record()
+        main_id = torch.cuda.current_stream().cuda_stream
+        waits = []
+        orig_wait_stream, orig_wait_event = torch.cuda.Stream.wait_stream, torch.cuda.Stream.wait_event
 
-        def last_tap(p):
-            main_done.record()          # on the caller's stream, after everything its backward queued there
-        last_tap._mia_side_aware = True
-        h = m2.backbone.conv_stem.weight.register_post_accumulate_grad_hook(last_tap)
-        t0 = time.perf_counter()
-        loss2.backward()
+        def wait_stream(self, other):
+            waits.append((self.cuda_stream, other.cuda_stream, len(red2._works)))
+            return orig_wait_stream(self, other)
+
+        def wait_event(self, ev):
+            waits.append((self.cuda_stream, None, len(red2._works)))
+            return orig_wait_event(self, ev)
+        torch.cuda.Stream.wait_stream, torch.cuda.Stream.wait_event = wait_stream, wait_event
+        try:
+            loss2.backward()
+        finally:
+            torch.cuda.Stream.wait_stream, torch.cuda.Stream.wait_event = orig_wait_stream, orig_wait_event
         assert len(red2._works) == len(red2.buckets)
-        while not main_done.query() and time.perf_counter() - t0 < 1.2:
-            time.sleep(0.005)
-        assert main_done.query(), "the caller's stream did not get through backward while the side stream was busy"
-        assert not side_done.query(), "the spin kernel ended early: the check proved nothing"
+        forks = [w for w in waits if w[0] != main_id]
+        joins = [w for w in waits if w[0] == main_id]
+        assert len(forks) > 50, "the weight gradients did not run on the second stream"
+        assert joins and all(w[2] == len(red2.buckets) for w in joins), \
+            f"the caller's stream waited for the side stream before every bucket was out: {joins}"
         red2.finish()
         torch.cuda.synchronize()
-        h.remove()
         for name, p in m2.named_parameters():
             assert torch.equal(p.grad, seen[name]), f"{name}: gradient changed when the exchange ran on the side stream"
         red2.remove()
