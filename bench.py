@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--linbn-min", type=int, default=0, help="A/B: smallest rows x expanded channels for that path")
     ap.add_argument("--no-fork", action="store_true", help="A/B switch: weight gradients on the main stream instead of the side stream")
     ap.add_argument("--kernel-table", action="store_true", help="also print a per-family timing table to stderr")
+    ap.add_argument("--nchw-input", action="store_true",
+                    help="A/B switch: feed float32 NCHW images (the reference loaders' form) instead of the "
+                         "channels-last compute-type images the preprocessing kernel can write directly")
     ap.add_argument("--graph", action="store_true",
                     help="time HIP-graph replays of the step (single GPU)")
     ap.add_argument("--graph-fork", action="store_true", help="with --graph: capture the weight-gradient fork/join")
@@ -128,13 +131,15 @@ def main():
     reducer.broadcast_parameters(model)
     opt = AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
 
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     # synthetic MRI-shaped batches, preprocessed on the device by the resize+normalise kernel, resident in HBM. The
     # steps rotate over NBATCH different batches so that the timed steps keep back-propagating a real gradient (one
     # fixed batch is memorised within the warm-up and the loss collapses to 0)
     xs, ys = [], []
     for i in range(NBATCH):
         raw = torch.from_numpy(phantom_batch(args.batch, 1234 + 1000 * i + rank)).to(dev)
-        xs.append(PP.resize_normalize(raw, (300, 300)))
+        # in the compute type and channels-last order: the form the stem reads without a conversion pass
+        xs.append(PP.resize_normalize(raw, (300, 300), out_dtype=None if args.nchw_input else cdt))
         ys.append(torch.from_numpy(np.random.default_rng(99 + 1000 * i + rank).integers(0, 4, args.batch)).to(dev))
     del raw
 

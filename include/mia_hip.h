@@ -224,6 +224,8 @@ int mia_softmax_ce(const float* logits, int ld, const long long* labels, int B, 
 /* ---- stem: timm conv_stem (3->40, k3 s2 p1) as im2col + mia_gemm_nt. x is NCHW fp32 (the tensor the
  *      reference feeds the model, train.py:345-351); col is [B*OH*OW][32], columns 27..31 zero. */
 int mia_stem_im2col(int dtype, const float* x, int B, int H, int W, void* col, void* stream);
+/* The same lowering from a channels-last image in the compute type, x [B,H,W,3] (dtype) -> col [B*OH*OW,32] (dtype). */
+int mia_stem_im2col_nhwc(int dtype, const void* x, int B, int H, int W, void* col, void* stream);
 
 /* fp32 master weight [R][Cc] -> compute-dtype copy [R][ldd] and/or transpose [Cc][ldt], zero padded. */
 int mia_cast_pad_transpose(int dtype, const float* src, int R, int Cc, void* dst, int ldd, void* dstT, int ldt,
@@ -238,6 +240,12 @@ int mia_cast_pad_transpose_multi(int dtype, int n, const void* const* src, const
  *      dst f32 [N,3,oh,ow]. mode 0: (x - 255*mean)*(1/(255*std)); mode 1: x/255. */
 int mia_resize_normalize_u8(const uint8_t* src, int N, int h, int w, int ch, float* dst, int oh, int ow,
                             const float* mean3, const float* std3, int mode, void* stream);
+/* The same transform with the result in the trunk's compute type and channels-last order, dst [N,oh,ow,3] in dtype
+ * (MIA_F32 / MIA_BF16): values are the float results above rounded once to dtype. This is the form
+ * mia_stem_im2col_nhwc reads, so the normalised image is written once at 6 bytes a pixel (bf16) and the first
+ * convolution (timm conv_stem, src/model.py:283-288) takes it without a layout or type conversion. */
+int mia_resize_normalize_u8_nhwc(const uint8_t* src, int N, int h, int w, int ch, void* dst, int dtype, int oh, int ow,
+                                 const float* mean3, const float* std3, int mode, void* stream);
 
 /* ---- zero-intensity slice filter. No counterpart in the reference (zi_remover.py:3-19 deletes Zone.Identifier
  *      files); specification: keep[z] = any(vol[z] != 0), idx = ascending kept indices, count[0] = their number.

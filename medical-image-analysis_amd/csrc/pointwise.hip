@@ -1130,6 +1130,62 @@ extern "C" int mia_stem_im2col(int dtype, const float* x, int B, int H, int W, v
     return 0;
 }
 
+// The same lowering from a channels-last image already in the compute type: x [B,H,W,3] (T) -> col [B*OH*OW, 32] (T),
+// same column order. A tap row of an output pixel is 9 contiguous elements (3 pixels x 3 channels) of the image,
+// where the NCHW form gathers 27 strided scalars; no conversion, the values are copied.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_im2col_nhwc_kernel(const T* __restrict__ x, int B, int H, int W, int OH,
+                                                               int OW, T* __restrict__ col) {
+    const long long total = (long long)B * OH * OW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ow = (int)(i % OW), oh = (int)((i / OW) % OH), b = (int)(i / ((long long)OW * OH));
+        T v[32];
+        T zero;
+        zero = from_f32<T>(0.f);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * 2 - 1 + kh;
+            const bool rok = ih >= 0 && ih < H;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * 2 - 1 + kw;
+                const bool ok = rok && iw >= 0 && iw < W;
+                const T* px = x + (((size_t)b * H + (rok ? ih : 0)) * W + (ok ? iw : 0)) * 3;
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) v[ci * 9 + kh * 3 + kw] = ok ? px[ci] : zero;
+            }
+        }
+#pragma unroll
+        for (int k = 27; k < 32; ++k) v[k] = zero;
+        T* o = col + (size_t)i * 32;
+        constexpr int PER16 = 16 / (int)sizeof(T);
+#pragma unroll
+        for (int k = 0; k < 32; k += PER16) {
+            uint4 w;
+            __builtin_memcpy(&w, &v[k], 16);
+            *reinterpret_cast<uint4*>(o + k) = w;
+        }
+    }
+}
+
+extern "C" int mia_stem_im2col_nhwc(int dtype, const void* x, int B, int H, int W, void* col, void* stream) {
+    MIA_CHECK_ARG(x && col && B > 0 && H > 0 && W > 0, "mia_stem_im2col_nhwc: bad arguments");
+    MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "mia_stem_im2col_nhwc: bad dtype %d", dtype);
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)B * OH * OW;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIA_BF16)
+        MIA_LAUNCH(stem_im2col_nhwc_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)x, B, H, W, OH,
+                   OW, (bf16_t*)col);
+    else
+        MIA_LAUNCH(stem_im2col_nhwc_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x, B, H, W, OH, OW,
+                   (float*)col);
+    MIA_CHECK_LAUNCH("mia_stem_im2col_nhwc");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight preparation: fp32 master [R][Cc] -> compute-dtype copy [R][ldd] and/or transpose [Cc][ldt],
 // zero-padded to the leading dimensions.

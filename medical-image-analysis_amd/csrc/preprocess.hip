@@ -30,10 +30,12 @@ __device__ __forceinline__ LinCoef lin_coef(int d, int src, int dst) {
     return c;
 }
 
-// src u8 [N,h,w,ch] (ch = 1 or 3) -> dst f32 [N,3,oh,ow]
+// src u8 [N,h,w,ch] (ch = 1 or 3) -> dst f32 [N,3,oh,ow] (OUT 0), bf16 [N,oh,ow,3] (OUT 1) or f32 [N,oh,ow,3] (OUT 2)
+template <int OUT>
 __global__ __launch_bounds__(256) void resize_normalize_kernel(const uint8_t* src, int N, int h, int w, int ch,
-                                                               float* dst, int oh, int ow, float m0, float m1, float m2,
+                                                               void* dstv, int oh, int ow, float m0, float m1, float m2,
                                                                float r0, float r1, float r2, int mode) {
+    float* dst = reinterpret_cast<float*>(dstv);
     const long long total = (long long)N * oh * ow;
     const float mm[3] = {m0, m1, m2}, rr[3] = {r0, r1, r2};
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -59,7 +61,9 @@ __global__ __launch_bounds__(256) void resize_normalize_kernel(const uint8_t* sr
             } else {
                 o = (float)v / 255.0f;
             }
-            dst[(((size_t)n * 3 + c) * oh + oy) * ow + ox] = o;
+            if constexpr (OUT == 0) dst[(((size_t)n * 3 + c) * oh + oy) * ow + ox] = o;
+            else if constexpr (OUT == 1) reinterpret_cast<bf16_t*>(dstv)[(size_t)i * 3 + c] = from_f32<bf16_t>(o);
+            else dst[(size_t)i * 3 + c] = o;
         }
     }
 }
@@ -68,10 +72,15 @@ __global__ __launch_bounds__(256) void resize_normalize_kernel(const uint8_t* sr
 // tables are computed once per workgroup, the source rows the tile needs are staged in LDS with 16-byte loads, and
 // every thread then produces four consecutive output pixels per channel (16-byte stores). Global memory sees only
 // streaming vector accesses; the twelve byte-sized taps per pixel are LDS reads.
+// OUT: 0 = float [N,3,oh,ow] (the tensor ToTensorV2 hands to the model); 1 = bf16 [N,oh,ow,3]; 2 = float [N,oh,ow,3]:
+// the channels-last forms are what the trunk's stem reads directly (mia_stem_im2col_nhwc), in the trunk's compute
+// type, so the normalised image is written once at 6 (or 12) bytes a pixel instead of 12 and never converted again.
 #define RZ_ROWS 20
-__global__ __launch_bounds__(256) void resize_normalize_tile_kernel(const uint8_t* src, int h, int w, int ch, float* dst,
+template <int OUT>
+__global__ __launch_bounds__(256) void resize_normalize_tile_kernel(const uint8_t* src, int h, int w, int ch, void* dstv,
                                                                     int oh, int ow, float m0, float m1, float m2, float r0,
                                                                     float r1, float r2, int mode) {
+    float* dst = reinterpret_cast<float*>(dstv);
     extern __shared__ __align__(16) uint8_t rz_lds[];
     int4* cxs = reinterpret_cast<int4*>(rz_lds);   // per output column: byte offset of tap 0, of tap 1, weights
     int4* cys = cxs + ow;                          // per output row of the tile: source rows, weights
@@ -130,26 +139,59 @@ __global__ __launch_bounds__(256) void resize_normalize_tile_kernel(const uint8_
                 o[c][j] = f;
             }
         }
+        if constexpr (OUT == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float* d = dst + (((size_t)n * 3 + c) * oh + oy) * ow + ox;
+            for (int c = 0; c < 3; ++c) {
+                float* d = dst + (((size_t)n * 3 + c) * oh + oy) * ow + ox;
+                if (vec_out) {
+                    *reinterpret_cast<float4*>(d) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (ox + j < ow) d[j] = o[c][j];
+                }
+            }
+        } else if constexpr (OUT == 1) {
+            // four pixels x three channels = 24 contiguous bytes, 8-byte aligned when ow % 4 == 0
+            bf16_t* d = reinterpret_cast<bf16_t*>(dstv) + (((size_t)n * oh + oy) * ow + ox) * 3;
             if (vec_out) {
-                *reinterpret_cast<float4*>(d) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+                uint2* d2 = reinterpret_cast<uint2*>(d);
+                d2[0] = make_uint2(pack_bf16x2(v2f{o[0][0], o[1][0]}), pack_bf16x2(v2f{o[2][0], o[0][1]}));
+                d2[1] = make_uint2(pack_bf16x2(v2f{o[1][1], o[2][1]}), pack_bf16x2(v2f{o[0][2], o[1][2]}));
+                d2[2] = make_uint2(pack_bf16x2(v2f{o[2][2], o[0][3]}), pack_bf16x2(v2f{o[1][3], o[2][3]}));
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (ox + j < ow) d[j] = o[c][j];
+                    if (ox + j < ow)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) d[j * 3 + c] = from_f32<bf16_t>(o[c][j]);
+            }
+        } else {
+            float* d = dst + (((size_t)n * oh + oy) * ow + ox) * 3;
+            if (vec_out) {
+                float4* d4 = reinterpret_cast<float4*>(d);
+                d4[0] = make_float4(o[0][0], o[1][0], o[2][0], o[0][1]);
+                d4[1] = make_float4(o[1][1], o[2][1], o[0][2], o[1][2]);
+                d4[2] = make_float4(o[2][2], o[0][3], o[1][3], o[2][3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ox + j < ow)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) d[j * 3 + c] = o[c][j];
             }
         }
     }
 }
 
 // mode 0: (x - 255*mean) * (1/(255*std));  mode 1: x / 255
-extern "C" int mia_resize_normalize_u8(const uint8_t* src, int N, int h, int w, int ch, float* dst, int oh, int ow,
-                                       const float* mean3, const float* std3, int mode, void* stream) {
-    MIA_CHECK_ARG(src && dst && N > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "mia_resize_normalize_u8: bad arguments");
-    MIA_CHECK_ARG(ch == 1 || ch == 3, "mia_resize_normalize_u8: channels must be 1 or 3, got %d", ch);
-    MIA_CHECK_ARG(mode == 1 || (mean3 && std3), "mia_resize_normalize_u8: normalise mode needs mean and std");
+// out_form 0: float [N,3,oh,ow]; 1: bf16 [N,oh,ow,3]; 2: float [N,oh,ow,3]
+static int resize_normalize_impl(const char* name, const uint8_t* src, int N, int h, int w, int ch, void* dst,
+                                 int out_form, int oh, int ow, const float* mean3, const float* std3, int mode,
+                                 void* stream) {
+    MIA_CHECK_ARG(src && dst && N > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "%s: bad arguments", name);
+    MIA_CHECK_ARG(ch == 1 || ch == 3, "%s: channels must be 1 or 3, got %d", name, ch);
+    MIA_CHECK_ARG(mode == 1 || (mean3 && std3), "%s: normalise mode needs mean and std", name);
     float m[3] = {0, 0, 0}, r[3] = {1, 1, 1};
     if (mode == 0) {
         for (int i = 0; i < 3; ++i) {
@@ -164,22 +206,47 @@ extern "C" int mia_resize_normalize_u8(const uint8_t* src, int N, int h, int w, 
     // row, monotone in the row index), one more for slack
     const long long src_rows = ((long long)(RZ_ROWS - 1) * h + oh - 1) / oh + 4;
     const long long lds = (long long)ow * 16 + RZ_ROWS * 16 + src_rows * (long long)w * ch + 16;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (lds <= 64 * 1024 && N <= 65535 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
         dim3 grid((unsigned)((oh + RZ_ROWS - 1) / RZ_ROWS), (unsigned)N);
-        MIA_LAUNCH(resize_normalize_tile_kernel, grid, dim3(256), (size_t)lds,
-                           reinterpret_cast<hipStream_t>(stream), src, h, w, ch, dst, oh, ow, m[0], m[1], m[2], r[0], r[1],
-                           r[2], mode);
-        MIA_CHECK_LAUNCH("mia_resize_normalize_u8");
+        if (out_form == 0)
+            MIA_LAUNCH(resize_normalize_tile_kernel<0>, grid, dim3(256), (size_t)lds, s, src, h, w, ch, dst, oh, ow, m[0],
+                       m[1], m[2], r[0], r[1], r[2], mode);
+        else if (out_form == 1)
+            MIA_LAUNCH(resize_normalize_tile_kernel<1>, grid, dim3(256), (size_t)lds, s, src, h, w, ch, dst, oh, ow, m[0],
+                       m[1], m[2], r[0], r[1], r[2], mode);
+        else
+            MIA_LAUNCH(resize_normalize_tile_kernel<2>, grid, dim3(256), (size_t)lds, s, src, h, w, ch, dst, oh, ow, m[0],
+                       m[1], m[2], r[0], r[1], r[2], mode);
+        MIA_CHECK_LAUNCH(name);
         return 0;
     }
     const long long total = (long long)N * oh * ow;
     long long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    MIA_LAUNCH(resize_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), src, N, h, w, ch, dst, oh, ow, m[0], m[1], m[2], r[0],
-                       r[1], r[2], mode);
-    MIA_CHECK_LAUNCH("mia_resize_normalize_u8");
+    if (out_form == 0)
+        MIA_LAUNCH(resize_normalize_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, src, N, h, w, ch, dst, oh, ow, m[0],
+                   m[1], m[2], r[0], r[1], r[2], mode);
+    else if (out_form == 1)
+        MIA_LAUNCH(resize_normalize_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, src, N, h, w, ch, dst, oh, ow, m[0],
+                   m[1], m[2], r[0], r[1], r[2], mode);
+    else
+        MIA_LAUNCH(resize_normalize_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, src, N, h, w, ch, dst, oh, ow, m[0],
+                   m[1], m[2], r[0], r[1], r[2], mode);
+    MIA_CHECK_LAUNCH(name);
     return 0;
+}
+
+extern "C" int mia_resize_normalize_u8(const uint8_t* src, int N, int h, int w, int ch, float* dst, int oh, int ow,
+                                       const float* mean3, const float* std3, int mode, void* stream) {
+    return resize_normalize_impl("mia_resize_normalize_u8", src, N, h, w, ch, dst, 0, oh, ow, mean3, std3, mode, stream);
+}
+
+extern "C" int mia_resize_normalize_u8_nhwc(const uint8_t* src, int N, int h, int w, int ch, void* dst, int dtype, int oh,
+                                            int ow, const float* mean3, const float* std3, int mode, void* stream) {
+    MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "mia_resize_normalize_u8_nhwc: bad dtype %d", dtype);
+    return resize_normalize_impl("mia_resize_normalize_u8_nhwc", src, N, h, w, ch, dst, dtype == MIA_BF16 ? 1 : 2, oh, ow,
+                                 mean3, std3, mode, stream);
 }
 
 // 8-bit result of the same resize, HWC with 3 channels (gray replicated): the input of the augmentation kernels

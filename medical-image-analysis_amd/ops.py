@@ -501,9 +501,15 @@ class LinBN:
 
 
 def stem_im2col(x, dtype):
+    """x [B,3,H,W]: float32 in NCHW order (what the reference's loaders hand over), or already in the compute type in
+    channels-last order (preprocess.resize_normalize(..., out_dtype=...)), which is read without any conversion."""
     B, _, H, W = x.shape
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     col = torch.empty((B * OH * OW, 32), dtype=dtype, device=x.device)
+    if x.dtype == dtype and x.stride() == (3 * H * W, 1, 3 * W, 3):
+        lib().mia_stem_im2col_nhwc(_DT[dtype], _p(x), B, H, W, _p(col), _stream())
+        return col, OH, OW
+    x = x.contiguous().float()
     lib().mia_stem_im2col(_DT[dtype], _p(x), B, H, W, _p(col), _stream())
     return col, OH, OW
 
@@ -603,7 +609,6 @@ class StemFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, gamma, beta, cfg):
         B = x.shape[0]
-        x = x.contiguous().float()
         col, OH, OW = stem_im2col(x, cfg.dtype)
         wp, _ = cast_weight(_w2d(w), cfg.dtype, pad_to=32)
         M = B * OH * OW

@@ -19,8 +19,14 @@ def _f3(v):
 
 
 def resize_normalize(images_u8: torch.Tensor, size: Tuple[int, int], mean=IMAGENET_MEAN, std=IMAGENET_STD,
-                     normalize: bool = True) -> torch.Tensor:
-    """uint8 [N,h,w,3] (RGB, HWC) or [N,h,w] / [N,h,w,1] (gray, replicated) on the device -> float32 [N,3,H,W]."""
+                     normalize: bool = True, out_dtype=None) -> torch.Tensor:
+    """uint8 [N,h,w,3] (RGB, HWC) or [N,h,w] / [N,h,w,1] (gray, replicated) on the device -> float32 [N,3,H,W].
+
+    out_dtype (torch.bfloat16 or torch.float32): the result in that type and in channels-last memory order instead
+    -- still a tensor of shape [N,3,H,W], so it is passed to the model like the default form, but stored [N,H,W,3].
+    That is the form the trunk's first convolution reads directly when out_dtype is the model's compute type: the
+    values are the float32 results rounded once to out_dtype, which is the rounding the trunk applies to a float32
+    input anyway, so the model's outputs are bit-identical either way."""
     if not images_u8.is_cuda or images_u8.dtype != torch.uint8:
         raise RuntimeError("resize_normalize expects a uint8 CUDA tensor")
     if images_u8.dim() == 3:
@@ -28,8 +34,16 @@ def resize_normalize(images_u8: torch.Tensor, size: Tuple[int, int], mean=IMAGEN
     images_u8 = images_u8.contiguous()
     N, h, w, ch = images_u8.shape
     oh, ow = int(size[0]), int(size[1])
-    out = torch.empty((N, 3, oh, ow), dtype=torch.float32, device=images_u8.device)
     m, s = _f3(mean), _f3(std)
+    if out_dtype is not None:
+        if out_dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError(f"resize_normalize: out_dtype must be float32 or bfloat16, got {out_dtype}")
+        out = torch.empty((N, oh, ow, 3), dtype=out_dtype, device=images_u8.device)
+        lib().mia_resize_normalize_u8_nhwc(_p(images_u8), N, h, w, ch, _p(out), 1 if out_dtype == torch.bfloat16 else 0,
+                                           oh, ow, ctypes.cast(m, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p),
+                                           0 if normalize else 1, _stream())
+        return out.permute(0, 3, 1, 2)
+    out = torch.empty((N, 3, oh, ow), dtype=torch.float32, device=images_u8.device)
     lib().mia_resize_normalize_u8(_p(images_u8), N, h, w, ch, _p(out), oh, ow, ctypes.cast(m, ctypes.c_void_p),
                                   ctypes.cast(s, ctypes.c_void_p), 0 if normalize else 1, _stream())
     return out
@@ -48,10 +62,10 @@ def zero_slice_filter(vol: torch.Tensor):
     if vol.dtype not in (torch.uint8, torch.int8, torch.int16, torch.uint16, torch.int32, torch.float32):
         raise TypeError(f"unsupported volume dtype {vol.dtype}")
     dev = vol.device
-    flags = torch.empty((N,), dtype=torch.int32, device=dev)
-    keep = torch.empty((N,), dtype=torch.bool, device=dev)      # one byte per slice, written as 0 / 1
-    idx = torch.empty((N,), dtype=torch.int32, device=dev)
-    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    # one allocation for the four small buffers (each allocator call costs the host as much as the kernel runs)
+    words = torch.empty((2 * N + 1 + (N + 3) // 4,), dtype=torch.int32, device=dev)
+    flags, idx, count = words[:N], words[N:2 * N], words[2 * N:2 * N + 1]
+    keep = words[2 * N + 1:].view(torch.bool)[:N]               # one byte per slice, written as 0 / 1
     lib().mia_zero_slice_filter(_p(vol), esz, 1 if is_float else 0, N, elems, _p(flags), _p(keep), _p(idx), _p(count),
                                 _stream())
     return keep, idx, count

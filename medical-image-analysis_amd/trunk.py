@@ -248,7 +248,7 @@ class EfficientNetB3Features(nn.Module):
     def _infer_nhwc(self, x) -> List[torch.Tensor]:
         fw = self._folded()
         B = x.shape[0]
-        col, OH, OW = ops.stem_im2col(x.contiguous().float(), self.compute_dtype)
+        col, OH, OW = ops.stem_im2col(x, self.compute_dtype)
         h, _ = ops.gemm_nt(col, fw[0], bias=fw[1], epi_act=ops.ACT_SILU)
         h = h.view(B, OH, OW, -1)
         feats, i = [], 2

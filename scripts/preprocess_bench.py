@@ -82,6 +82,15 @@ for batch in (128, 512, 2048):
                       "frac_hbm": round(nbytes / t / 1e9 / HBM_PEAK, 3), "cpu_numpy_images_per_s": round(1 / t_c, 1),
                       "cpu_cores": 1}), flush=True)
 
+    # the channels-last bf16 form the trunk's stem reads directly: half the write bytes
+    out_cl = PP.resize_normalize(img, (300, 300), out_dtype=torch.bfloat16)
+    assert torch.equal(out_cl, out.to(torch.bfloat16)), "channels-last bf16 output differs from the rounded float32 one"
+    t = gpu_time(lambda: PP.resize_normalize(img, (300, 300), out_dtype=torch.bfloat16))
+    nbytes = img.numel() + out_cl.numel() * 2
+    print(json.dumps({"case": "resize_normalize", "images": batch, "in": "256x256x3 u8", "out": "300x300x3 bf16 (NHWC)",
+                      "gpu_us": round(t * 1e6, 1), "images_per_s": round(batch / t), "GB_per_s": round(nbytes / t / 1e9, 1),
+                      "frac_hbm": round(nbytes / t / 1e9 / HBM_PEAK, 3)}), flush=True)
+
 from mia_amd.augment import TrainTransform
 from oracle import augment_ref as A
 for batch in (128, 512):

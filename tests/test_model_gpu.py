@@ -367,3 +367,36 @@ def test_c5_batch512_fp32_inference_top1_agreement(size):
     decided = (top2[:, 0] - top2[:, 1]) > 0.1 * scale
     assert int(decided.sum()) > 0
     assert bool((lb.argmax(1)[decided] == lr.argmax(1)[decided]).all())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_channels_last_input_in_compute_dtype_gives_identical_results(dtype):
+    """The trunk reads a channels-last image that is already in its compute type without conversion
+    (preprocess.resize_normalize(..., out_dtype=...) -> mia_stem_im2col_nhwc). The rounding to the compute type is the
+    one the float32 NCHW path applies in its own im2col, so logits and every gradient are bit-identical."""
+    from mia_amd import preprocess as PP
+    from mia_amd.head_ops import CrossEntropyLoss
+    torch.manual_seed(11)
+    model = FoundationModel(backbone="efficientnet_b3", pretrained=False, dropout=0.0,
+                            classification_heads={"synthetic": 4}, use_attention=True, compute_dtype=dtype).cuda().train()
+    raw = torch.randint(0, 256, (4, 80, 72, 3), dtype=torch.uint8, device="cuda")
+    y = torch.tensor([0, 1, 2, 3], device="cuda")
+    cdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    x_ref = PP.resize_normalize(raw, (96, 96))
+    x_cl = PP.resize_normalize(raw, (96, 96), out_dtype=cdt)
+    crit = CrossEntropyLoss()
+    outs = []
+    for x in (x_ref, x_cl):
+        for m in model.modules():       # same running statistics at the start of both passes
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        model.zero_grad(set_to_none=True)
+        logits = model(x, "classification", "synthetic")
+        crit(logits, y).backward()
+        outs.append((logits.detach().clone(), [p.grad.clone() for p in model.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
+    model.eval()
+    with torch.no_grad():
+        assert torch.equal(model(x_ref, "classification", "synthetic"), model(x_cl, "classification", "synthetic"))

@@ -35,6 +35,23 @@ def test_resize_normalize_bit_exact(shape, out, normalize):
     np.testing.assert_array_equal(got, exp)
 
 
+@pytest.mark.parametrize("shape,out", [((4, 256, 256, 3), (300, 300)), ((2, 97, 131, 3), (300, 300)),
+                                       ((1, 1200, 1000, 3), (300, 300)), ((5, 256, 256, 1), (301, 299)),
+                                       ((3, 64, 64, 3), (9, 6))])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("normalize", [True, False])
+def test_resize_normalize_channels_last_compute_dtype(shape, out, dtype, normalize):
+    """The channels-last output in the trunk's compute type holds the float32 results of the default form rounded
+    once to that type (bit-exact after the same rounding), has the shape of the default form and NHWC storage."""
+    rng = np.random.default_rng(4)
+    img = torch.from_numpy(rng.integers(0, 256, shape, dtype=np.uint8)).cuda()
+    ref = PP.resize_normalize(img, out, normalize=normalize)
+    got = PP.resize_normalize(img, out, normalize=normalize, out_dtype=dtype)
+    assert got.dtype == dtype and tuple(got.shape) == tuple(ref.shape)
+    assert got.permute(0, 2, 3, 1).is_contiguous()
+    assert torch.equal(got, ref.to(dtype))
+
+
 def test_resize_gray_replicates_channels():
     g = phantom(3, 256, 256, 1234)
     got = PP.resize_normalize(torch.from_numpy(g).cuda(), (300, 300)).cpu().numpy()
