@@ -135,6 +135,8 @@ int mia_img_colsum(int dtype, const void* Y, const void* Wt, int B, int HW, int 
 int mia_se_gate_fwd(const float* pool_part, int B, int splits, int HW, int C, int RD, const float* Wr,
                     const float* br, const float* WeT, const float* be, float* pooled, float* hpre, float* gate,
                     void* stream);
+/* mia_se_gate_bwd: dpre2 may be the same array as dgate_part when splits == 1 and the array already holds dpre2 (see
+ * mia_se_bwd_sums); it is then read, not rewritten. */
 int mia_se_gate_bwd(const float* dgate_part, int B, int splits, int HW, int C, int RD, const float* Wr,
                     const float* WeT, const float* gate, const float* hpre, const float* pooled, float* dpre2,
                     float* dpre1, float* dpool, float* dWr, float* dbr, float* dWe, float* dbe, void* stream);
@@ -148,8 +150,12 @@ int mia_se_param_grad(int B, int C, int RD, const float* dpre2, const float* dpr
  * as out [5][B][splits][C]. Plane 0 is the dgate_part of mia_se_gate_bwd; mia_se_bn_combine turns planes 1..4 plus
  * (gate, dpool) into the partial slab part [B][2][C] of mia_bn_finalize_bwd (timm SqueezeExcite + BatchNormAct2d
  * backward, done by autograd in the reference). */
+/* gate (nullable, needs splits == 1): plane 0 comes out multiplied by gate*(1-gate), the sigmoid's derivative, i.e.
+ * as the dpre2 of mia_se_gate_bwd -- pass that plane there as BOTH dgate_part and dpre2 and the entry point skips its
+ * own pass over it. */
 int mia_se_bwd_sums(int dtype, const void* Y, const void* dZ, int B, int HW, int C, const float* scale,
-                    const float* shift, const float* mean, const float* rstd, int splits, float* out, void* stream);
+                    const float* shift, const float* mean, const float* rstd, int splits, float* out,
+                    const float* gate, void* stream);
 int mia_se_bn_combine(const float* sums, int B, int splits, int C, const float* gate, const float* dpool, float* part,
                       void* stream);
 

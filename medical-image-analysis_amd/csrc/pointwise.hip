@@ -481,7 +481,8 @@ extern "C" int mia_img_colsum(int dtype, const void* Y, const void* Wt, int B, i
 template <typename T>
 __global__ __launch_bounds__(256) void se_bwd_sums_kernel(const T* Y, const T* dZ, int B, int HW, int C, int CB,
                                                           int splits, const float* scale, const float* shift,
-                                                          const float* mean, const float* rstd, float* out) {
+                                                          const float* mean, const float* rstd, float* out,
+                                                          const float* gate) {
     __shared__ float red[256 * 8];
     const int tid = threadIdx.x;
     const RowMap m = make_rowmap(C, CB, blockIdx.y, tid);
@@ -526,13 +527,23 @@ __global__ __launch_bounds__(256) void se_bwd_sums_kernel(const T* Y, const T* d
     const f4 q0 = to_f4(a0), q1 = to_f4(a1), q2 = to_f4(a2), q3 = to_f4(a3), q4 = to_f4(a4);
     const size_t plane = (size_t)B * splits * C, row = ((size_t)b * splits + sp) * C;
     block_colsum2(red, m, tid, q0, q1, out + row, out + plane + row);
+    if (gate) {
+        // one split per image: plane 0 is then the whole gradient w.r.t. the gate, and the sigmoid's derivative
+        // g(1-g) goes in here (each thread revisits the entries it has just written), which makes the plane the
+        // dpre2 of mia_se_gate_bwd and saves that entry point a launch
+        for (int ch = tid; ch < m.cbv; ch += 256) {
+            const float g = gate[(size_t)b * C + m.c0 + ch];
+            out[row + m.c0 + ch] *= g * (1.f - g);
+        }
+    }
     block_colsum2(red, m, tid, q2, q3, out + 2 * plane + row, out + 3 * plane + row);
     block_colsum2(red, m, tid, q4, q4, out + 4 * plane + row, nullptr);
 }
 
 extern "C" int mia_se_bwd_sums(int dtype, const void* Y, const void* dZ, int B, int HW, int C, const float* scale,
                                const float* shift, const float* mean, const float* rstd, int splits, float* out,
-                               void* stream) {
+                               const float* gate, void* stream) {
+    MIA_CHECK_ARG(!gate || splits == 1, "mia_se_bwd_sums: the gate factor needs one split per image");
     MIA_CHECK_ARG(Y && dZ && out && scale && shift && mean && rstd && B > 0 && HW > 0 && C > 0 && C % 4 == 0 &&
                       splits > 0 && splits <= HW,
                   "mia_se_bwd_sums: bad arguments");
@@ -542,10 +553,10 @@ extern "C" int mia_se_bwd_sums(int dtype, const void* Y, const void* dZ, int B, 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIA_BF16)
         MIA_LAUNCH(se_bwd_sums_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)Y, (const bf16_t*)dZ, B, HW,
-                           C, CB, splits, scale, shift, mean, rstd, out);
+                           C, CB, splits, scale, shift, mean, rstd, out, gate);
     else
         MIA_LAUNCH(se_bwd_sums_kernel<float>, grid, dim3(256), 0, s, (const float*)Y, (const float*)dZ, B, HW, C,
-                           CB, splits, scale, shift, mean, rstd, out);
+                           CB, splits, scale, shift, mean, rstd, out, gate);
     MIA_CHECK_LAUNCH("mia_se_bwd_sums");
     return 0;
 }
@@ -773,9 +784,11 @@ __global__ __launch_bounds__(256) void se_prep_kernel(const float* part, int spl
 // d[b][j] = sum_c Wm[j][c] * v[b][c]; one wave per (4 rows j) x (8 images), lanes stride over c.
 // mode 0: pre = d + bias[j] -> out[b][j]                     (forward hidden pre-activation)
 // mode 1: out[b][j] = d * silu'(hpre[b][j])                  (backward through the hidden SiLU)
+// vscale: v is used as v*vscale (the forward takes the per-image channel SUMS and folds the 1/HW of the mean in here);
+// vout (nullable): the waves of the first row tile also write v*vscale there (the pooled means the backward needs).
 __global__ __launch_bounds__(256) void se_reduce_c_kernel(const float* __restrict__ Wm, const float* __restrict__ v,
                                                           int B, int C, int RD, const float* bias, const float* hpre,
-                                                          int mode, float* out) {
+                                                          int mode, float* out, float vscale, float* vout) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int njt = (RD + SE_JT - 1) / SE_JT;
     const int wid = blockIdx.x * 4 + wave;
@@ -804,13 +817,18 @@ __global__ __launch_bounds__(256) void se_reduce_c_kernel(const float* __restric
         for (int a = 0; a < SE_JT; ++a)
 #pragma unroll
             for (int e = 0; e < SE_IB; ++e) acc[a][e] += w[a] * x[e];
+        if (vout && jt == 0) {
+#pragma unroll
+            for (int e = 0; e < SE_IB; ++e)
+                if (b0 + e < B) vout[(size_t)(b0 + e) * C + c] = x[e] * vscale;
+        }
     }
     float mine = 0.f;
 #pragma unroll
     for (int a = 0; a < SE_JT; ++a)
 #pragma unroll
         for (int e = 0; e < SE_IB; ++e) {
-            const float t = wave_sum(acc[a][e]);
+            const float t = wave_sum(acc[a][e]) * vscale;
             if (lane == a * SE_IB + e) mine = t;
         }
     if (lane < SE_JT * SE_IB) {
@@ -866,11 +884,18 @@ extern "C" int mia_se_gate_fwd(const float* pool_part, int B, int splits, int HW
                   "mia_se_gate_fwd: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (se_wide(C, RD)) {
-        MIA_LAUNCH(se_prep_kernel, dim3(cdiv((long long)B * C, 256)), dim3(256), 0, s, pool_part, splits,
-                           1.0f / (float)HW, C, B * C, (const float*)nullptr, 0, pooled);
         const int waves = cdiv(RD, SE_JT) * cdiv(B, SE_IB);
-        MIA_LAUNCH(se_reduce_c_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, s, Wr, pooled, B, C, RD, br,
-                           (const float*)nullptr, 0, hpre);
+        if (splits == 1) {
+            // one partial row per image: the "sum of the splits" is the row itself, and the 1/HW of the mean rides in
+            // the first FC (which is linear in its input) -- one launch less on the block's critical chain
+            MIA_LAUNCH(se_reduce_c_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, s, Wr, pool_part, B, C, RD, br,
+                       (const float*)nullptr, 0, hpre, 1.0f / (float)HW, pooled);
+        } else {
+            MIA_LAUNCH(se_prep_kernel, dim3(cdiv((long long)B * C, 256)), dim3(256), 0, s, pool_part, splits,
+                       1.0f / (float)HW, C, B * C, (const float*)nullptr, 0, pooled);
+            MIA_LAUNCH(se_reduce_c_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, s, Wr, pooled, B, C, RD, br,
+                       (const float*)nullptr, 0, hpre, 1.f, (float*)nullptr);
+        }
         MIA_LAUNCH(se_expand_kernel, dim3(cdiv(C, 256), cdiv(B, SE_IB)), dim3(256), (size_t)RD * SE_IB * 4, s,
                            WeT, hpre, B, C, RD, be, 1.f, 0, gate);
     } else {
@@ -884,9 +909,12 @@ extern "C" int mia_se_gate_fwd(const float* pool_part, int B, int splits, int HW
 
 // backward through the gate for one image: dgate (summed partials) -> dpre2 [B,C], dpre1 [B,RD],
 // dpool [B,C] (already divided by HW: it is added to every pixel's gradient)
+// pre: dgate_part already holds dpre2 (mia_se_bwd_sums multiplied the sigmoid's derivative in): splits == 1 and
+// dpre2 is the same array, which is then neither recomputed nor rewritten.
 __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* dgate_part, int splits, float inv_hw, int C,
                                                           int RD, const float* Wr, const float* WeT, const float* gate,
-                                                          const float* hpre, float* dpre2, float* dpre1, float* dpool) {
+                                                          const float* hpre, float* dpre2, float* dpre1, float* dpool,
+                                                          int pre) {
     extern __shared__ float sm[];
     float* d2 = sm;      // [C]
     float* d1 = sm + C;  // [RD]
@@ -894,10 +922,14 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* dgate_par
     for (int c = tid; c < C; c += 256) {
         float s = 0.f;
         for (int k = 0; k < splits; ++k) s += dgate_part[((size_t)b * splits + k) * C + c];
-        const float g = gate[(size_t)b * C + c];
-        const float v = s * g * (1.f - g);
-        d2[c] = v;
-        dpre2[(size_t)b * C + c] = v;
+        if (pre) {
+            d2[c] = s;
+        } else {
+            const float g = gate[(size_t)b * C + c];
+            const float v = s * g * (1.f - g);
+            d2[c] = v;
+            dpre2[(size_t)b * C + c] = v;
+        }
     }
     __syncthreads();
     for (int j = wave; j < RD; j += 4) {
@@ -958,18 +990,22 @@ extern "C" int mia_se_gate_bwd(const float* dgate_part, int B, int splits, int H
                       RD > 0 && HW > 0 && (!dWr == !dbr) && (!dWr == !dWe) && (!dWr == !dbe),
                   "mia_se_gate_bwd: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // dpre2 == dgate_part: the caller's one partial row per image already is dpre2 (see mia_se_bwd_sums' gate argument)
+    const int pre = (dpre2 == dgate_part) ? 1 : 0;
+    MIA_CHECK_ARG(!pre || splits == 1, "mia_se_gate_bwd: dpre2 may alias dgate_part only with one split per image");
     if (se_wide(C, RD)) {
-        MIA_LAUNCH(se_prep_kernel, dim3(cdiv((long long)B * C, 256)), dim3(256), 0, s, dgate_part, splits, 0.f,
-                           C, B * C, gate, 1, dpre2);
+        if (!pre)
+            MIA_LAUNCH(se_prep_kernel, dim3(cdiv((long long)B * C, 256)), dim3(256), 0, s, dgate_part, splits, 0.f,
+                       C, B * C, gate, 1, dpre2);
         const int waves = cdiv(RD, SE_JT) * cdiv(B, SE_IB);
         MIA_LAUNCH(se_reduce_c_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, s, WeT, dpre2, B, C, RD,
-                           (const float*)nullptr, hpre, 1, dpre1);
+                           (const float*)nullptr, hpre, 1, dpre1, 1.f, (float*)nullptr);
         MIA_LAUNCH(se_expand_kernel, dim3(cdiv(C, 256), cdiv(B, SE_IB)), dim3(256), (size_t)RD * SE_IB * 4, s,
                            Wr, dpre1, B, C, RD, (const float*)nullptr, 1.0f / (float)HW, 1, dpool);
     } else {
         const size_t lds = (size_t)(C + RD) * 4;
         MIA_LAUNCH(se_gate_bwd_kernel, dim3(B), dim3(256), lds, s, dgate_part, splits, 1.0f / (float)HW, C, RD,
-                           Wr, WeT, gate, hpre, dpre2, dpre1, dpool);
+                           Wr, WeT, gate, hpre, dpre2, dpre1, dpool, pre);
     }
     if (dWr)
         MIA_LAUNCH(se_param_grad_kernel, dim3(cdiv((long long)C * RD, 64)), dim3(256), 0, s, B, C, RD, dpre2,

@@ -387,26 +387,39 @@ def affine2(x, a, d, *, y=None, b=None, res=None, act=ACT_NONE, out=None):
     return out
 
 
+def _img_splits(B, HW, C):
+    """Row splits per image of the per-image reductions: ~2048 workgroups of >= 64 rows each on the large maps; ONE
+    on maps of up to 400 pixels (19x19, 10x10), where the squeeze-excite gate kernels then take the per-image row as
+    it is and need no launch to add splits up."""
+    if HW <= 400:
+        return 1
+    ncb = -(-C // 256)
+    return max(1, min(HW // 64, 64, -(-2048 // (B * ncb))))
+
+
 def img_colsum(y, wt, scale, shift, act):
     B, H, W, C = y.shape
     HW = H * W
-    ncb = -(-C // 256)
-    splits = max(1, min(HW // 64, 64, -(-2048 // (B * ncb))))  # ~2048 workgroups, >= 64 rows each
+    splits = _img_splits(B, HW, C)
     out = torch.empty((B, splits, C), dtype=torch.float32, device=y.device)
     _launch("img_colsum", y.numel() * y.element_size() * (2 if wt is not None else 1), lib().mia_img_colsum,
             _DT[y.dtype], _p(y), _p(wt), B, HW, C, _p(scale), _p(shift), act, splits, _p(out), _stream())
     return out
 
 
-def se_bwd_sums(y, dz, stats):
-    """One pass over (y, dz): [5, B, splits, C] per-image sums for the squeeze-excite and BatchNorm backward."""
+def se_bwd_sums(y, dz, stats, gate=None):
+    """One pass over (y, dz): [5, B, splits, C] per-image sums for the squeeze-excite and BatchNorm backward.
+    gate [B, C]: on maps that take one split per image, plane 0 comes out multiplied by gate*(1-gate), i.e. as the
+    dpre2 of se_gate_bwd (which recognises it by out.pre_scaled); on larger maps the argument is ignored."""
     B, H, W, C = y.shape
     HW = H * W
-    ncb = -(-C // 256)
-    splits = max(1, min(HW // 64, 64, -(-2048 // (B * ncb))))
+    splits = _img_splits(B, HW, C)
     out = torch.empty((5, B, splits, C), dtype=torch.float32, device=y.device)
+    pre = gate is not None and splits == 1
     _launch("se_bwd_sums", y.numel() * y.element_size() * 2, lib().mia_se_bwd_sums, _DT[y.dtype], _p(y), _p(dz), B, HW,
-            C, _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), splits, _p(out), _stream())
+            C, _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), splits, _p(out), _p(gate) if pre else None,
+            _stream())
+    out.pre_scaled = pre
     return out
 
 
@@ -439,12 +452,13 @@ def se_gate_fwd(pool_part, hw, wr, br, weT, be):
     return pooled, hpre, gate
 
 
-def se_gate_bwd(dgate_part, hw, wr, weT, gate, hpre, pooled):
-    """Backward through the gate: -> (dpool, dpre2, dpre1); the parameter gradients come from se_param_grad."""
+def se_gate_bwd(dgate_part, hw, wr, weT, gate, hpre, pooled, pre_scaled=False):
+    """Backward through the gate: -> (dpool, dpre2, dpre1); the parameter gradients come from se_param_grad.
+    pre_scaled: dgate_part [B,1,C] already is dpre2 (se_bwd_sums with its gate argument)."""
     B, splits, C = dgate_part.shape
     RD = wr.shape[0]
     dev = dgate_part.device
-    dpre2 = torch.empty((B, C), dtype=torch.float32, device=dev)
+    dpre2 = dgate_part.view(B, C) if pre_scaled else torch.empty((B, C), dtype=torch.float32, device=dev)
     dpre1 = torch.empty((B, RD), dtype=torch.float32, device=dev)
     dpool = torch.empty((B, C), dtype=torch.float32, device=dev)
     lib().mia_se_gate_bwd(_p(dgate_part), B, splits, hw, C, RD, _p(wr), _p(weT), _p(gate), _p(hpre), _p(pooled),
@@ -722,9 +736,9 @@ class MBConvFn(torch.autograd.Function):
         dz, _ = gemm_nt(dy3, ctx.wprojT)
         dz = dz.view(B, OH, OW, Cm)
         # ---- squeeze-excite backward ----
-        sums = se_bwd_sums(y2, dz, st2)
+        sums = se_bwd_sums(y2, dz, st2, gate=gate)
         wr, weT = _w2d(w_ser), ctx.weT
-        dpool, dpre2, dpre1 = se_gate_bwd(sums[0], OH * OW, wr, weT, gate, hpre, pooled)
+        dpool, dpre2, dpre1 = se_gate_bwd(sums[0], OH * OW, wr, weT, gate, hpre, pooled, pre_scaled=sums.pre_scaled)
         with side_scope(x.device, wparams, (dpre2, dpre1, pooled, hpre), work):
             dwr, dbr, dwe, dbe = se_param_grad(dpre2, dpre1, pooled, hpre)
         # ---- bn after depthwise (+SiLU): its reductions come from the same per-image sums ----

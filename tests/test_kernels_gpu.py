@@ -329,6 +329,39 @@ def test_se_gate_fwd_bwd(C, RD, B, hw):
         assert relerr(mine, ref) < 1e-4
 
 
+@pytest.mark.parametrize("C,RD,B,side", [(576, 24, 9, 19), (1392, 58, 16, 10), (2304, 96, 5, 10), (144, 6, 4, 10),
+                                         (40, 10, 3, 20)])
+def test_se_single_split_paths_match_general_ones(C, RD, B, side):
+    """On maps of up to 400 pixels the per-image reductions use one row per image, the forward gate takes that row as
+    it is (the 1/HW of the mean rides in the first FC) and the backward takes plane 0 of se_bwd_sums already multiplied
+    by the sigmoid's derivative. Same results as the general path fed the same sums as a 3-way split (1e-6)."""
+    hw = side * side
+    y = rnd(B, side, side, C, seed=1)
+    dz = rnd(B, side, side, C, seed=2)
+    st = torch.stack([rnd(C, seed=3).abs() + 0.5, rnd(C, seed=4), rnd(C, seed=5), rnd(C, seed=6).abs() + 0.5]).contiguous()
+    wr, br = rnd(RD, C, seed=7, scale=C ** -0.5), rnd(RD, seed=8, scale=0.1)
+    we, be = rnd(C, RD, seed=9, scale=RD ** -0.5), rnd(C, seed=10, scale=0.1)
+    weT = we.t().contiguous()
+    pool1 = ops.img_colsum(y, None, st[0], st[1], ops.ACT_SILU)
+    assert pool1.shape[1] == 1
+    # the general path: the same sums presented as three splits
+    pool3 = torch.stack([pool1[:, 0] * 0.5, pool1[:, 0] * 0.25, pool1[:, 0] * 0.25], 1).contiguous()
+    pooled1, hpre1, gate1 = ops.se_gate_fwd(pool1, hw, wr, br, weT, be)
+    pooled3, hpre3, gate3 = ops.se_gate_fwd(pool3, hw, wr, br, weT, be)
+    for a, b in ((pooled1, pooled3), (hpre1, hpre3), (gate1, gate3)):
+        assert relerr(a, b) < 1e-6
+    sums = ops.se_bwd_sums(y, dz, st, gate=gate1)
+    plain = ops.se_bwd_sums(y, dz, st)
+    assert sums.pre_scaled and not plain.pre_scaled
+    assert torch.equal(sums[1:], plain[1:])
+    assert relerr(sums[0, :, 0], plain[0, :, 0] * gate1 * (1 - gate1)) < 1e-6
+    dpool1, dpre2_1, dpre1_1 = ops.se_gate_bwd(sums[0], hw, wr, weT, gate1, hpre1, pooled1, pre_scaled=True)
+    dpool0, dpre2_0, dpre1_0 = ops.se_gate_bwd(plain[0], hw, wr, weT, gate1, hpre1, pooled1)
+    assert dpre2_1.data_ptr() == sums[0].data_ptr()
+    for a, b in ((dpool1, dpool0), (dpre2_1, dpre2_0), (dpre1_1, dpre1_0)):
+        assert relerr(a, b) < 1e-6
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("H,W", [(300, 300), (64, 64), (33, 47)])
 def test_stem_im2col_gemm_equals_conv(dtype, H, W):
