@@ -47,7 +47,7 @@ int mia_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void*
  * The reduction over M is split across workgroups. With a workspace (ws != NULL, at least
  * mia_gemm_tn_ws_floats(...) floats; or ws == NULL and ws_floats < 0 when that count is 0) every split writes its
  * partial tile to ws and a second kernel adds the partials in a fixed order: bit-reproducible results, O is
- * OVERWRITTEN and need not be initialised. With ws == NULL and ws_floats == 0 the partials are added into O with
+ * OVERWRITTEN and need not be initialised; ws and O must be 16-byte aligned and ldo a multiple of 4. With ws == NULL and ws_floats == 0 the partials are added into O with
  * float atomics: O must then be zero-filled (or hold a gradient to accumulate into) and the rounding varies from run
  * to run. */
 int mia_gemm_tn(int dtype, const void* G, int ldg, const void* X, int ldx, float* O, int ldo, int M, int N, int K,

@@ -1091,7 +1091,7 @@ extern "C" int mia_dwconv_fwd(int dtype, const void* x, int B, int H, int W, int
     p.tiles_h = cdiv(p.OH, p.TH); p.tiles_w = cdiv(p.OW, p.TW);
     const int total = B * p.tiles_h * p.tiles_w;
     int gx = total < 8192 ? total : 8192;
-        if (gx >= 16) gx &= ~7;   // a multiple of eight: sibling channel blocks share an XCD (dw_decode_block)
+    if (gx >= 16) gx &= ~7;   // a multiple of eight: sibling channel blocks share an XCD (dw_decode_block)
     if (stats) {
         if (gx > part_rows) gx = part_rows;
         if (gx < part_rows) {  // rows no workgroup owns must still read as zero

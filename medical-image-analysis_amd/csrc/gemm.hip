@@ -1054,6 +1054,7 @@ extern "C" int mia_gemm_tn(int dtype, const void* G, int ldg, const void* X, int
                       "mia_gemm_tn: workspace of %lld floats needed (mia_gemm_tn_ws_floats), %lld given", t.ws_floats,
                       ws_floats);
         MIA_CHECK_ARG(ldo % 4 == 0 && ((uintptr_t)O % 16) == 0, "mia_gemm_tn: O must be 16-byte aligned with ldo %% 4 == 0");
+        MIA_CHECK_ARG(((uintptr_t)ws % 16) == 0, "mia_gemm_tn: the workspace must be 16-byte aligned (it is read as float4)");
         p.det = 1; p.ws = ws;
     }
     const long long splits = t.splits;

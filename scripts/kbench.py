@@ -47,6 +47,23 @@ for mode in ("fwd", "bwdd", "bwdw"):
     CASES[f"dw{mode}_s6"] = (lambda m=mode: dw_case(10, 2304, 3, 1, m))    # stage 6.x
     CASES[f"dw{mode}_s0"] = (lambda m=mode: dw_case(150, 40, 3, 1, m))     # stage 0.0
 
+def dw_ablate(H, C, k, s, pro, stats):
+    x = rnd(B, H, H, C)
+    w = torch.randn(C, k * k, device="cuda")
+    sc, sh = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1
+    pad = (k - 1) // 2
+    OH = (H + 2 * pad - k) // s + 1
+    rows_out = ops.part_rows(B * ((OH * OH + 127) // 128))
+    nbytes = (x.numel() + B * OH * OH * C) * 2
+    return (lambda: ops.dwconv_fwd(x, w, k, s, pscale=sc if pro else None, pshift=sh if pro else None,
+                                   stats_rows=rows_out if stats else 0)), nbytes
+
+
+CASES["dwfwd_s1_nopro"] = lambda: dw_ablate(75, 192, 3, 1, False, True)
+CASES["dwfwd_s1_nostats"] = lambda: dw_ablate(75, 192, 3, 1, True, False)
+CASES["dwfwd_s1_bare"] = lambda: dw_ablate(75, 192, 3, 1, False, False)
+
+
 def gemm_case(M, N, K, pro, stats, act=None, use_gate=True):
     a, b = rnd(M, K), rnd(N, K)
     sc, sh = torch.rand(K, device="cuda") + 0.5, torch.randn(K, device="cuda") * 0.1
