@@ -76,6 +76,22 @@ int mia_dwconv_bwd_data(int dtype, const void* dy, int B, int H, int W, int C, c
  * are allowed (H, W: the forward convolution's INPUT map): passing exactly this count as part_rows avoids the extra
  * zero-fill launch for rows no workgroup owns. Returns a count (-1: bad shape). */
 int mia_dwconv_part_rows(int dtype, int kind, int B, int H, int W, int C, int K, int S, int cap);
+/* The stride-2 data gradient of an inverted-residual block (timm InvertedResidual: conv_pw -> bn1 -> conv_dw) fused
+ * with the two products of conv_pw's backward that consume it, for blocks whose bn1 backward is carried through
+ * conv_pw (mia_bn_lin_prep / mia_bn_lin_fix). With g = dx * silu'(yfwd*escale+eshift) as in mia_dwconv_bwd_data, g
+ * itself is never written; instead
+ *     dxp[B*H*W, Cin] = g . ((gamma*erstd) o wexp)          t1[C, Cin] (fp32) = g^T x
+ * wexp [C, Cin] and x [B*H*W, Cin] are bf16, 16-byte aligned like dxp. stats as in mia_dwconv_bwd_data (required).
+ * ws: fp32 scratch of rows*C*Cin floats, rows = mia_dwconv_bwd_data_lin_rows(B, H, W, K, C, part_rows) (a count; -1:
+ * bad shape). mia_dwconv_bwd_data_lin_supported is 1 for the shapes a kernel exists for (bf16, stride 2,
+ * K = 3, C = 144, Cin in {8, 16, 24, 32}): EfficientNet-B3's block 1.0, the largest expanded tensor of the trunk. */
+int mia_dwconv_bwd_data_lin_supported(int dtype, int C, int K, int S, int Cin);
+int mia_dwconv_bwd_data_lin_rows(int B, int H, int W, int K, int C, int cap);
+int mia_dwconv_bwd_data_lin(int dtype, const void* dy, int B, int H, int W, int C, const float* w, int K, int S,
+                            const void* yfwd, const float* escale, const float* eshift, const float* emean,
+                            const float* erstd, const float* gamma, const void* wexp, const void* x, int Cin,
+                            void* dxp, float* t1, float* stats, int part_rows, float* ws, long long ws_floats,
+                            void* stream);
 /* dw[C][k*k] (fp32) = sum dy * pro(x). ws: fp32 scratch of ws_floats >= C*k*k floats (256*C*k*k lets every
  * workgroup row keep its own partial; fewer rows are used when it is smaller). */
 int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int W, int C, const float* pscale,

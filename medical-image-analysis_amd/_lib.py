@@ -43,6 +43,11 @@ def parse_header(path=HEADER):
     return protos
 
 
+# int-returning entries whose value is a count or a yes/no, not an error code
+_COUNTS = ("mia_version", "mia_cbam_ws_floats", "mia_dwconv_part_rows", "mia_dwconv_bwd_data_lin_supported",
+           "mia_dwconv_bwd_data_lin_rows")
+
+
 class MiaError(RuntimeError):
     pass
 
@@ -59,7 +64,7 @@ class _Lib:
             fn = getattr(self._dll, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
-            if restype is ctypes.c_int and name not in ("mia_version", "mia_cbam_ws_floats", "mia_dwconv_part_rows"):
+            if restype is ctypes.c_int and name not in _COUNTS:
                 setattr(self, name, self._checked(name, fn))
             else:
                 setattr(self, name, fn)

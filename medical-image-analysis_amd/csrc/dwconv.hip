@@ -618,6 +618,303 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_s2_kernel(DwParams p) {
     if (p.stats) dw_write_stats(p, red, tid, nvec, npt, c0, cbv, st_s, st_q, slot);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stride-2 data gradient of an inverted-residual block whose BatchNorm backward is carried through the expansion
+// convolution. There the gradient g = dA * silu'(z) has exactly two consumers, both linear in it:
+//     dxp = g (ca o Wexp)     [pixels x Cin]     ca = gamma * rstd of the expansion's BatchNorm
+//     T1  = g^T x             [C x Cin]
+// so g is never written to memory. A workgroup owns ALL C channels of a tile of 4 x 6 cells (96 dA pixels), keeps
+// the tile's g in LDS as bf16 (the rounding the stored tensor would have had) and feeds the matrix cores from there:
+// k-contiguous rows for the first product, transposing LDS reads for the second, whose accumulator stays in
+// registers for the whole kernel and goes to a per-workgroup slab at the end (summed in a fixed order afterwards).
+// Per tile: stage dY and x, compute g with the vector ALUs exactly as dwconv_bwd_data_s2_kernel does, then
+// 15 + 15 (C = 144) matrix instructions per wave. HBM sees dY (with halo), the forward tensor, x and dxp -- the
+// expanded gradient's write and its two re-reads are gone.
+// ------------------------------------------------------------------------------------------------
+struct DwLinParams {
+    const bf16_t* x;      // block input [B*H*W][Cin]
+    const bf16_t* wexp;   // expansion weights [C][Cin]
+    const float* gamma;   // [C]
+    bf16_t* dxp;          // [B*H*W][Cin]
+    float* slab;          // [gx][C][Cin]
+    int Cin;
+};
+constexpr int DWL_TH = 4, DWL_TW = 6;                 // tile in cells
+constexpr int DWL_NPX = 4 * DWL_TH * DWL_TW;          // dA pixels per tile (rows of the g tile)
+constexpr int DWL_LDX = 40;                           // LDS row stride of the x tile (32 columns + 8)
+constexpr int DWL_LDC = 24;                           // LDS row stride of a wave's output strip (16 columns + 8)
+typedef __attribute__((ext_vector_type(8))) __bf16 dw_bf16x8;
+typedef __attribute__((ext_vector_type(8))) short dw_s16x8;
+
+// reduction-major LDS image ([red][col]) -> matrix operand: base = &tile[k0][col0], LD = row stride in elements
+__device__ __forceinline__ dw_bf16x8 dwl_load_t(const bf16_t* base, int LD, int lane) {
+    typedef __attribute__((address_space(3))) dw_s16x4 lds_s16x4;
+    const int i = lane & 15, g = lane >> 4;
+    const bf16_t* p0 = base + (8 * g + (i >> 2)) * LD + 4 * (i & 3);
+    const dw_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+    const dw_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * LD));
+    const dw_s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(dw_bf16x8, r);
+}
+
+static size_t dwl_lds_bytes(int K, int C) {
+    const int LDG = ((C + 31) & ~31) + 8;
+    return (size_t)K * K * C * 4 + (size_t)(DWL_TH + 2) * (DWL_TW + 2) * C * 2 + (size_t)DWL_NPX * LDG * 2 +
+           (size_t)DWL_NPX * DWL_LDX * 2 + (size_t)32 * LDG * 2 + (size_t)4 * 16 * DWL_LDC * 2;
+}
+
+template <int K, int C>
+__global__ __launch_bounds__(256, 2) void dwconv_bwd_lin_s2_kernel(DwParams p, DwLinParams q) {
+    typedef bf16_t T;
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int TH = DWL_TH, TW = DWL_TW, IHT = TH + 2, IWT = TW + 2, NPX = DWL_NPX, PW2 = 2 * TW;
+    constexpr int CP = (C + 31) & ~31, LDG = CP + 8, LDX = DWL_LDX;
+    constexpr int CT = C / 16, MTW = (CT + 1) / 2;     // 16-channel row tiles of T1; per wave
+    constexpr int nvec = C / 4, npt = 256 / nvec;
+    static_assert(C % 16 == 0 && C <= 256, "channel count");
+    constexpr int NV = (IHT * IWT + npt - 1) / npt;   // staged dY pixels per thread
+    static_assert(256 * 8 * 4 <= NPX * LDG * 2, "the end-of-kernel reduction aliases the g tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wsm = reinterpret_cast<float*>(smem);       // [K*K][C]
+    T* tile = reinterpret_cast<T*>(wsm + K * K * C);   // [IHT*IWT][C]
+    T* Gs = tile + IHT * IWT * C;                      // [NPX][LDG]   g of the tile; columns C.. stay zero
+    T* Xs = Gs + NPX * LDG;                            // [NPX][LDX]   x of the tile; columns Cin.. stay zero
+    T* Wc = Xs + NPX * LDX;                            // [32][LDG]    (ca o Wexp)^T; rows Cin.. and columns C.. zero
+    T* Cw = Wc + 32 * LDG;                             // [4 waves][16][LDC]
+    float* red = reinterpret_cast<float*>(Gs);
+
+    const T* __restrict__ dy = reinterpret_cast<const T*>(p.x);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = blockIdx.x;
+    const int Cin = q.Cin, XC = Cin >> 3;              // 16-byte chunks per x row
+    const int cv = tid % nvec, pt = tid / nvec;
+    const int c = cv * 4;
+    const bool cvalid = pt < npt;
+    for (int i = tid; i < K * K * C; i += 256) {
+        const int t = i / C, cc = i - t * C;
+        wsm[i] = p.w[(size_t)cc * (K * K) + t];
+    }
+    {
+        uint4* z = reinterpret_cast<uint4*>(Gs);
+        constexpr int n16 = (NPX * LDG + NPX * LDX + 32 * LDG + 4 * 16 * DWL_LDC) / 8;
+        for (int i = tid; i < n16; i += 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    for (int i = tid; i < C * Cin; i += 256) {
+        const int cc = i / Cin, j = i - cc * Cin;
+        Wc[j * LDG + cc] = from_f32<T>(to_f32<T>(q.wexp[i]) * (q.gamma[cc] * p.erstd[cc]));
+    }
+    const f22 zero22 = {v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+    f22 es = zero22, eh = zero22, em = zero22, er = zero22;
+    if (cvalid) {
+        es = load22<float>(p.escale + c); eh = load22<float>(p.eshift + c);
+        em = load22<float>(p.emean + c); er = load22<float>(p.erstd + c);
+    }
+    f22 st_s = zero22, st_q = zero22;
+    dw_f32x4 acc_t[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) acc_t[i] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int tiles_per_img = p.tiles_h * p.tiles_w;
+    const int total = p.B * tiles_per_img;
+    constexpr int patches_w = TW / 2, npatch = TH * patches_w;
+
+    TileRegs<T, NV> regs;
+    uint4 xr[2];
+    auto fetch = [&](int work) {
+        const int b = work / tiles_per_img;
+        const int tr = work - b * tiles_per_img;
+        const int trh = tr / p.tiles_w;
+        const int r0 = trh * TH, q0 = (tr - trh * p.tiles_w) * TW;
+        dw_tile_fetch<T, NV>(regs, dy + (size_t)b * p.OH * p.OW * C, IHT, IWT, r0 - 1, q0 - 1, p.OH, p.OW, C, c, true,
+                                 pt, npt);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * 256;
+            const int row = e / XC, ch = e - row * XC;
+            const int lh = row / PW2, lw = row - lh * PW2;
+            const int ih = r0 * 2 + lh, iw = q0 * 2 + lw;
+            xr[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (row < NPX && ih < p.H && iw < p.W)
+                xr[u] = *reinterpret_cast<const uint4*>(q.x + ((size_t)(b * p.H + ih) * p.W + iw) * Cin + ch * 8);
+        }
+    };
+    // The forward tensor at this thread's output pixels of a tile (the epilogue's operand), loaded a phase ahead:
+    // issued before the matrix phase of the previous tile, used in the vector phase of this one. With two workgroups
+    // per CU there are too few waves to hide a global load issued where it is needed. Addresses are clamped into
+    // the image so that the loads need no branches; values outside are ignored by the epilogue.
+    constexpr int NIT = (npatch + npt - 1) / npt;      // patches per thread and tile
+    uint2 yr[NIT][2][4];
+    auto fetch_y = [&](int work) {
+        if (!cvalid) return;
+        const int b = work / tiles_per_img;
+        const int tr = work - b * tiles_per_img;
+        const int trh = tr / p.tiles_w;
+        const int r0 = trh * TH, q0 = (tr - trh * p.tiles_w) * TW;
+        const T* yimg = reinterpret_cast<const T*>(p.yfwd) + (size_t)b * p.H * p.W * C + c;
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int patch = pt + u * npt;
+            const int ph = patch / patches_w, pw = patch - ph * patches_w;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                int ih = (r0 + ph) * 2 + pr;
+                ih = ih < p.H ? ih : p.H - 1;
+#pragma unroll
+                for (int x_ = 0; x_ < 4; ++x_) {
+                    int iw = (q0 + pw * 2) * 2 + x_;
+                    iw = iw < p.W ? iw : p.W - 1;
+                    yr[u][pr][x_] = *reinterpret_cast<const uint2*>(yimg + (unsigned)((ih * p.W + iw) * C));
+                }
+            }
+        }
+    };
+    const TileWalk walk = make_tile_walk(total, slot, gridDim.x);
+    if (walk.first < walk.count) {
+        fetch(walk.base + walk.first);
+        fetch_y(walk.base + walk.first);
+    }
+    for (int wi = walk.first; wi < walk.count; wi += walk.stride) {
+        const int work = walk.base + wi;
+        const int b = work / tiles_per_img;
+        const int tr = work - b * tiles_per_img;
+        const int trh = tr / p.tiles_w;
+        const int r0 = trh * TH, q0 = (tr - trh * p.tiles_w) * TW;
+        __syncthreads();   // every wave is past the previous tile's matrix phase: all three tiles are free
+        dw_tile_commit<T, NV>(regs, tile, IHT * IWT, cv, pt, npt, C, false, zero22, zero22);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * 256;
+            const int row = e / XC, ch = e - row * XC;
+            if (row < NPX) *reinterpret_cast<uint4*>(Xs + row * LDX + ch * 8) = xr[u];
+        }
+        __syncthreads();
+        if (wi + walk.stride < walk.count) fetch(work + walk.stride);
+        // ---- vector phase: g of the tile into LDS ----
+        if (cvalid) {
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int patch = pt + u * npt;
+                if (patch >= npatch) break;
+                const int ph = patch / patches_w, pw = patch - ph * patches_w;
+                const int rl = ph, ql = pw * 2;
+                f22 in[3][4];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        in[a][j] = load22<T>(tile + (unsigned)(((rl + a) * IWT + ql + j) * C + c));
+                f22 acc[2][4];
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                    for (int x_ = 0; x_ < 4; ++x_) acc[pr][x_] = zero22;
+#pragma unroll
+                for (int kh = 0; kh < K; ++kh) {
+                    const int pr = (kh + PAD) & 1;
+                    const int dh = (pr + PAD - kh) / 2;
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw) {
+                        const int pc = (kw + PAD) & 1;
+                        const int dw = (pc + PAD - kw) / 2;
+                        const f22 wv = load22<float>(wsm + (unsigned)((kh * K + kw) * C + c));
+#pragma unroll
+                        for (int cell = 0; cell < 2; ++cell)
+                            fma22(acc[pr][cell * 2 + pc], in[dh + 1][cell + dw + 1], wv);
+                    }
+                }
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int lh = rl * 2 + pr;
+                    const int ih = r0 * 2 + lh;
+#pragma unroll
+                    for (int x_ = 0; x_ < 4; ++x_) {
+                        const int lw = ql * 2 + x_;
+                        const int iw = q0 * 2 + lw;
+                        const f22 yv = Raw4T<T>::unpack22(yr[u][pr][x_]);
+                        const f22 v = acc[pr][x_];
+                        f22 g;
+                        g.lo = v.lo * silu_grad2(yv.lo * es.lo + eh.lo);
+                        g.hi = v.hi * silu_grad2(yv.hi * es.hi + eh.hi);
+                        if (!(ih < p.H && iw < p.W)) g = zero22;
+                        st_s.lo += g.lo; st_s.hi += g.hi;
+                        st_q.lo += g.lo * ((yv.lo - em.lo) * er.lo);
+                        st_q.hi += g.hi * ((yv.hi - em.hi) * er.hi);
+                        store22<T>(Gs + (unsigned)((lh * PW2 + lw) * LDG + c), g);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one patch at a time: interleaving two doubles the live registers
+            }
+        }
+        if (wi + walk.stride < walk.count) fetch_y(work + walk.stride);
+        __syncthreads();
+        // ---- matrix phase ----
+        const int nt = wave & 1, mh = wave >> 1;
+        {
+            // dxp rows of the tile = Gs [96 x CP] . Wc^T [CP x 32]; this wave: column tile nt, row tiles mh, mh+2, mh+4
+            dw_f32x4 acc[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[i] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+            const T* bbase = Wc + (nt * 16 + (lane & 15)) * LDG + 8 * (lane >> 4);
+            const T* abase = Gs + (mh * 16 + (lane & 15)) * LDG + 8 * (lane >> 4);
+#pragma unroll
+            for (int kk = 0; kk < CP / 32; ++kk) {
+                const dw_bf16x8 bf = *reinterpret_cast<const dw_bf16x8*>(bbase + kk * 32);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const dw_bf16x8 af = *reinterpret_cast<const dw_bf16x8*>(abase + i * 32 * LDG + kk * 32);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[i], 0, 0, 0);
+                }
+            }
+            T* cw = Cw + wave * 16 * DWL_LDC;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cw[((lane >> 4) * 4 + r) * DWL_LDC + (lane & 15)] = from_f32<T>(acc[i][r]);
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 32) {
+                    const int row = lane >> 1, half = lane & 1;
+                    const int pp = (mh + 2 * i) * 16 + row;
+                    const int lh = pp / PW2, lw = pp - lh * PW2;
+                    const int ih = r0 * 2 + lh, iw = q0 * 2 + lw;
+                    const int col = nt * 16 + half * 8;
+                    if (ih < p.H && iw < p.W && col < Cin)
+                        *reinterpret_cast<uint4*>(q.dxp + ((size_t)(b * p.H + ih) * p.W + iw) * Cin + col) =
+                            *reinterpret_cast<const uint4*>(cw + row * DWL_LDC + half * 8);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        {
+            // T1 += Gs^T [C x 96] . Xs [96 x 32]; this wave: column tile nt, row tiles mh, mh+2, ...
+            const T* xb = Xs + nt * 16;
+#pragma unroll
+            for (int kk = 0; kk < NPX / 32; ++kk) {
+                const dw_bf16x8 bf = dwl_load_t(xb + kk * 32 * LDX, LDX, lane);
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) {
+                    if (mh + 2 * i < CT) {
+                        const dw_bf16x8 af = dwl_load_t(Gs + kk * 32 * LDG + (mh + 2 * i) * 16, LDG, lane);
+                        acc_t[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc_t[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    {
+        const int nt = wave & 1, mh = wave >> 1;
+        const int j = nt * 16 + (lane & 15);
+        float* dst = q.slab + (size_t)slot * C * Cin;
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+            if (mh + 2 * i < CT && j < Cin) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[((mh + 2 * i) * 16 + (lane >> 4) * 4 + r) * Cin + j] = acc_t[i][r];
+            }
+    }
+    dw_write_stats(p, red, tid, nvec, npt, 0, C, st_s, st_q, slot);
+}
+
 // weight gradient: dW[c][kh][kw] = sum_{b,oh,ow} dY[b,oh,ow,c] * pro(x)[b, oh*S+kh-PAD, ow*S+kw-PAD, c]
 // A thread owns ONE tap row kh of one 4-channel vector (K accumulators), so the register footprint stays small
 // for 5x5 kernels too; the K tap rows of a channel vector are K different threads reading the same staged tiles.
@@ -1176,6 +1473,78 @@ extern "C" int mia_dwconv_bwd_data(int dtype, const void* dy, int B, int H, int 
         }
     }
     MIA_CHECK_LAUNCH("mia_dwconv_bwd_data");
+    return 0;
+}
+
+// Shapes dwconv_bwd_lin_s2_kernel is built for (1 = yes).
+extern "C" int mia_dwconv_bwd_data_lin_supported(int dtype, int C, int K, int S, int Cin) {
+    // (A 5x5 / 192-channel build for block 2.0 was measured too: its 100 KB of LDS leave one workgroup per CU and the
+    // fused kernel then takes 582 us against 433 us for the three separate ones.)
+    return dtype == MIA_BF16 && S == 2 && K == 3 && C == 144 && Cin > 0 && Cin <= 32 && Cin % 8 == 0;
+}
+
+// Workgroups (= statistics rows written = slab rows) the fused launch uses when the caller allows `cap` of them.
+extern "C" int mia_dwconv_bwd_data_lin_rows(int B, int H, int W, int K, int C, int cap) {
+    if (B <= 0 || H <= 0 || W <= 0 || cap <= 0 || (K != 3 && K != 5)) return -1;
+    const int pad = (K - 1) / 2;
+    const int OH = (H + 2 * pad - K) / 2 + 1, OW = (W + 2 * pad - K) / 2 + 1;
+    const int total = B * cdiv(OH, DWL_TH) * cdiv(OW, DWL_TW);
+    const int per_cu = (int)(160 * 1024 / dwl_lds_bytes(K, C));
+    int gx = 256 * (per_cu < 1 ? 1 : per_cu);
+    if (gx > total) gx = total;
+    if (gx > cap) gx = cap;
+    if (gx >= 16) gx &= ~7;
+    return gx;
+}
+
+// Stride-2 data gradient with the fused silu' epilogue of mia_dwconv_bwd_data, but instead of the gradient g itself
+// its two linear images leave the kernel (see dwconv_bwd_lin_s2_kernel):
+//   dxp [B*H*W, Cin] = g . ((gamma*erstd) o wexp)       t1 [C, Cin] fp32 = g^T x
+// wexp [C, Cin] and x [B*H*W, Cin] in bf16. stats [part_rows][2][C] as in mia_dwconv_bwd_data. ws: fp32 scratch of
+// at least rows*C*Cin floats, rows = mia_dwconv_bwd_data_lin_rows(..., part_rows).
+extern "C" int mia_dwconv_bwd_data_lin(int dtype, const void* dy, int B, int H, int W, int C, const float* w, int K,
+                                       int S, const void* yfwd, const float* escale, const float* eshift,
+                                       const float* emean, const float* erstd, const float* gamma, const void* wexp,
+                                       const void* x, int Cin, void* dxp, float* t1, float* stats, int part_rows,
+                                       float* ws, long long ws_floats, void* stream) {
+    if (dw_common_checks("mia_dwconv_bwd_data_lin", dtype, B, H, W, C, K, S)) return -1;
+    MIA_CHECK_ARG(mia_dwconv_bwd_data_lin_supported(dtype, C, K, S, Cin),
+                  "mia_dwconv_bwd_data_lin: no kernel for dtype=%d C=%d K=%d S=%d Cin=%d", dtype, C, K, S, Cin);
+    MIA_CHECK_ARG(dy && w && yfwd && escale && eshift && emean && erstd && gamma && wexp && x && dxp && t1 && stats && ws,
+                  "mia_dwconv_bwd_data_lin: null operand");
+    MIA_CHECK_ARG(part_rows > 0 && part_rows <= 65535, "mia_dwconv_bwd_data_lin: bad part_rows");
+    MIA_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dxp % 16) == 0, "mia_dwconv_bwd_data_lin: x and dxp must be 16-byte aligned");
+    const int pad = (K - 1) / 2;
+    DwParams p = {};
+    p.x = dy; p.w = w; p.B = B; p.H = H; p.W = W; p.C = C;
+    p.OH = (H + 2 * pad - K) / 2 + 1; p.OW = (W + 2 * pad - K) / 2 + 1;
+    p.yfwd = yfwd; p.escale = escale; p.eshift = eshift; p.emean = emean; p.erstd = erstd; p.stats = stats;
+    p.CB = C; p.TH = DWL_TH; p.TW = DWL_TW; p.tiles_h = cdiv(p.OH, DWL_TH); p.tiles_w = cdiv(p.OW, DWL_TW);
+    const int gx = mia_dwconv_bwd_data_lin_rows(B, H, W, K, C, part_rows);
+    MIA_CHECK_ARG(gx > 0 && (long long)gx * C * Cin <= ws_floats, "mia_dwconv_bwd_data_lin: workspace of %lld floats is too small for %d rows",
+                  ws_floats, gx);
+    p.gx = gx; p.ncb = 1;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (gx < part_rows) {
+        hipError_t e = mia_zero_words(stats + (size_t)gx * 2 * C, (long long)(part_rows - gx) * 2 * C, s);
+        MIA_CHECK_ARG(e == hipSuccess, "mia_dwconv_bwd_data_lin: zero fill failed: %s", hipGetErrorString(e));
+    }
+    DwLinParams q = {};
+    q.x = (const bf16_t*)x; q.wexp = (const bf16_t*)wexp; q.gamma = gamma; q.dxp = (bf16_t*)dxp; q.slab = ws; q.Cin = Cin;
+    const size_t lds = dwl_lds_bytes(K, C);
+    {
+        auto kern = dwconv_bwd_lin_s2_kernel<3, 144>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        MIA_LAUNCH(kern, dim3((unsigned)gx), dim3(256), lds, s, p, q);
+    }
+    MIA_CHECK_LAUNCH("mia_dwconv_bwd_data_lin");
+    const long long n = (long long)C * Cin;
+    MIA_LAUNCH(slab_reduce_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, s, ws, gx, n, t1);
+    MIA_CHECK_LAUNCH("mia_dwconv_bwd_data_lin");
     return 0;
 }
 

@@ -313,6 +313,29 @@ def dwconv_bwd_data(dy, w, k, s, in_hw, *, yfwd=None, escale=None, eshift=None, 
     return dx, part
 
 
+def dwconv_bwd_data_lin_ok(dtype, C, k, s, Cin):
+    return bool(lib().mia_dwconv_bwd_data_lin_supported(_DT[dtype], C, k, s, Cin))
+
+
+def dwconv_bwd_data_lin(dy, w, k, s, x, *, yfwd, st, gamma, wexp, stats_rows):
+    """The stride-2 data gradient g of mia_dwconv_bwd_data (fused silu' epilogue, st = the expansion BatchNorm's
+    (scale, shift, mean, rstd)) consumed in the same kernel, never stored:
+    -> (dxp [M,Cin] = g . ((gamma*rstd) o wexp), t1 [C,Cin] fp32 = g^T x, partial sums [rows,2,C])."""
+    B, OH, OW, C = dy.shape
+    _, H, W, Cin = x.shape
+    dev = dy.device
+    rows = lib().mia_dwconv_bwd_data_lin_rows(B, H, W, k, C, stats_rows)
+    part = torch.empty((rows, 2, C), dtype=torch.float32, device=dev)
+    ws = torch.empty((rows * C * Cin,), dtype=torch.float32, device=dev)
+    dxp = torch.empty((B * H * W, Cin), dtype=dy.dtype, device=dev)
+    t1 = torch.empty((C, Cin), dtype=torch.float32, device=dev)
+    _launch("dwconv_bwd_data_lin", (dy.numel() + yfwd.numel() + 2 * x.numel()) * dy.element_size(),
+            lib().mia_dwconv_bwd_data_lin, _DT[dy.dtype], _p(dy), B, H, W, C, _p(w), k, s, _p(yfwd), _p(st[0]), _p(st[1]),
+            _p(st[2]), _p(st[3]), _p(gamma), _p(wexp), _p(x), Cin, _p(dxp), _p(t1), _p(part), rows, _p(ws), ws.numel(),
+            _stream())
+    return dxp, t1, part
+
+
 def dwconv_bwd_weight(x, dy, k, s, *, pscale=None, pshift=None):
     B, H, W, C = x.shape
     dw = torch.empty((C, 1, k, k), dtype=torch.float32, device=x.device)
@@ -508,6 +531,8 @@ class LinBN:
     # extra small launches cost more than the three passes they save
     MIN_ELEMS = 100_000_000
     MAX_CIN = 64
+    # stride-2 blocks: compute the two products inside the depthwise data-gradient kernel (mia_dwconv_bwd_data_lin)
+    fused = True
 
     @classmethod
     def use(cls, M, Cm, Cin):
@@ -750,10 +775,26 @@ class MBConvFn(torch.autograd.Function):
             # depthwise data gradient with fused silu' and bn1 partials
             with side_scope(x.device, wparams, (y1, dy2, st1), work):
                 ddw = dwconv_bwd_weight(y1, dy2, k, s, pscale=st1[0], pshift=st1[1])
+            x2d = x.view(M, Cin)
+            if (LinBN.fused and not cfg.has_skip and LinBN.use(M, Cm, Cin)
+                    and dwconv_bwd_data_lin_ok(dt, Cm, k, s, Cin)):
+                # the expanded gradient g is consumed inside the kernel that computes it: only its images under the
+                # two linear maps of the expansion's backward (and the BatchNorm sums) reach memory
+                dxp, t1, part = dwconv_bwd_data_lin(dy2, wdw, k, s, x, yfwd=y1, st=st1, gamma=g1, wexp=ctx.wexp,
+                                                    stats_rows=rows_in)
+                c1 = bn_finalize_bwd(part, M, g1, st1, training)
+                _, S, r = bn_lin_prep(ctx.wexp, c1)
+                with side_scope(x.device, wparams, (t1, x, c1, ctx.wexp), work):
+                    G = gemm_tn(x2d, x2d)
+                    cs = img_colsum(x, None, None, None, ACT_NONE).sum((0, 1))
+                    dwexp = bn_lin_fix(t1, ctx.wexp, c1, G, cs)
+                dx, _ = gemm_nt(x2d, S, bias=r, add=dxp)
+                dx = dx.view(B, H, W, Cin)
+                return (dx, dwexp.view_as(w_exp), c1[0], c1[1], ddw, c2[0], c2[1], dwr.view_as(w_ser), dbr,
+                        dwe.view_as(w_see), dbe, dwproj.view_as(w_proj), c3[0], c3[1], None)
             g1t, part = dwconv_bwd_data(dy2, wdw, k, s, (H, W), yfwd=y1, escale=st1[0], eshift=st1[1], emean=st1[2],
                                         erstd=st1[3], stats_rows=rows_in)
             c1 = bn_finalize_bwd(part, M, g1, st1, training)
-            x2d = x.view(M, Cin)
             if LinBN.use(M, Cm, Cin):
                 # dy1 = ca*g + cb*y1 + cd is never formed: both products that consume it are linear in it
                 g2d = g1t.view(M, Cm)

@@ -47,6 +47,35 @@ for mode in ("fwd", "bwdd", "bwdw"):
     CASES[f"dw{mode}_s6"] = (lambda m=mode: dw_case(10, 2304, 3, 1, m))    # stage 6.x
     CASES[f"dw{mode}_s0"] = (lambda m=mode: dw_case(150, 40, 3, 1, m))     # stage 0.0
 
+def dwlin_case(H, C, k, Cin, fused):
+    """Stride-2 data gradient + the two products of the expansion's backward: one fused kernel, or the three
+    separate ones it replaces."""
+    y1 = rnd(B, H, H, C)
+    xin = rnd(B, H, H, Cin)
+    w = torch.randn(C, k * k, device="cuda")
+    wexp = rnd(C, Cin)
+    st = torch.stack([torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1,
+                      torch.randn(C, device="cuda") * 0.1, torch.rand(C, device="cuda") + 0.5])
+    gamma = torch.rand(C, device="cuda") + 0.5
+    OH = (H + 2 * ((k - 1) // 2) - k) // 2 + 1
+    dy = rnd(B, OH, OH, C)
+    rows_in = ops.part_rows(B * ((H * H + 127) // 128))
+    M = B * H * H
+    nbytes = (dy.numel() + y1.numel() + 2 * xin.numel()) * 2
+    if fused:
+        return (lambda: ops.dwconv_bwd_data_lin(dy, w, k, 2, xin, yfwd=y1, st=st, gamma=gamma, wexp=wexp,
+                                                stats_rows=rows_in)), nbytes
+    wcaT = wexp.t().contiguous()
+    def sep():
+        g, _ = ops.dwconv_bwd_data(dy, w, k, 2, (H, H), yfwd=y1, escale=st[0], eshift=st[1], emean=st[2], erstd=st[3],
+                                   stats_rows=rows_in)
+        ops.gemm_nt(g.view(M, C), wcaT)
+        ops.gemm_tn(g.view(M, C), xin.view(M, Cin))
+    return sep, nbytes
+
+CASES["dwlin_s10"] = lambda: dwlin_case(150, 144, 3, 24, True)
+CASES["dwlin_s10_sep"] = lambda: dwlin_case(150, 144, 3, 24, False)
+
 def dw_ablate(H, C, k, s, pro, stats):
     x = rnd(B, H, H, C)
     w = torch.randn(C, k * k, device="cuda")

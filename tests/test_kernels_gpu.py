@@ -203,6 +203,44 @@ def test_dwconv_bwd(dtype, k, s, B, H, W, C):
     assert relerr(dw, wr.grad) < tol(dtype, 5e-5, 2e-2)
 
 
+@pytest.mark.parametrize("k,B,H,W,C,Cin", [(3, 2, 37, 41, 144, 24), (3, 1, 8, 6, 144, 8), (3, 3, 150, 150, 144, 24),
+                                            (3, 2, 75, 75, 144, 16), (3, 1, 9, 13, 144, 32), (3, 40, 50, 50, 144, 32)])
+def test_dwconv_bwd_data_lin_matches_the_unfused_products(k, B, H, W, C, Cin):
+    """The fused stride-2 data gradient never stores g; its two images g.(ca o W) and g^T x and the BatchNorm partial
+    sums must equal what the separate kernels compute from the stored (bf16-rounded) g: same products, same rounding
+    of g, only the order of the fp32 additions differs. Against an fp32 torch reference as well."""
+    dtype = torch.bfloat16
+    pad = (k - 1) // 2
+    OH, OW = (H + 2 * pad - k) // 2 + 1, (W + 2 * pad - k) // 2 + 1
+    M = B * H * W
+    y1 = rnd(B, H, W, C, seed=1, dtype=dtype)
+    w = rnd(C, 1, k, k, seed=2, scale=1.0 / k).reshape(C, k * k).contiguous()
+    sc, sh = rnd(C, seed=3).abs() + 0.5, rnd(C, seed=4, scale=0.3)
+    mean, rstd = rnd(C, seed=6, scale=0.2), rnd(C, seed=7).abs() + 0.5
+    gamma = rnd(C, seed=8).abs() + 0.5
+    dy = rnd(B, OH, OW, C, seed=5, dtype=dtype)
+    wexp = rnd(C, Cin, seed=9, scale=0.2, dtype=dtype)
+    x = rnd(B, H, W, Cin, seed=10, dtype=dtype)
+    assert ops.dwconv_bwd_data_lin_ok(dtype, C, k, 2, Cin)
+    st = torch.stack([sc, sh, mean, rstd])
+    g, part_ref = ops.dwconv_bwd_data(dy, w, k, 2, (H, W), yfwd=y1, escale=sc, eshift=sh, emean=mean, erstd=rstd,
+                                      stats_rows=64)
+    wcaT = (wexp.float() * (gamma * rstd)[:, None]).to(dtype).t().contiguous()
+    dxp_ref, _ = ops.gemm_nt(g.view(M, C), wcaT)
+    t1_ref = ops.gemm_tn(g.view(M, C), x.view(M, Cin))
+    dxp, t1, part = ops.dwconv_bwd_data_lin(dy, w, k, 2, x, yfwd=y1, st=st, gamma=gamma, wexp=wexp, stats_rows=512)
+    torch.cuda.synchronize()
+    assert dxp.shape == dxp_ref.shape and t1.shape == t1_ref.shape
+    scale = dxp_ref.float().abs().max().item()
+    assert (dxp.float() - dxp_ref.float()).abs().max().item() <= 2.0 ** -7 * scale   # one bf16 step at the largest value
+    assert relerr(dxp.float(), dxp_ref.float()) < 2e-3
+    assert relerr(t1, t1_ref) < 1e-4
+    assert relerr(part.sum(0), part_ref.sum(0)) < 1e-4
+    # independent fp32 reference of the two products (g from the library's own stored tensor)
+    assert relerr(dxp.float(), g.view(M, C).float() @ wcaT.float().t()) < 5e-3
+    assert relerr(t1, g.view(M, C).float().t() @ x.view(M, Cin).float()) < 1e-4
+
+
 # ------------------------------------------------------------------ BN / SE / elementwise
 @pytest.mark.parametrize("training", [True, False])
 def test_bn_finalize_fwd_matches_torch(training):
