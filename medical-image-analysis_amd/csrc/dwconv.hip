@@ -62,6 +62,23 @@ __device__ __forceinline__ void dw_epilogue_store(const DwParams& p, unsigned id
     }
 }
 
+// The same epilogue with the forward value already in registers. The data-gradient kernels load it well before the
+// point of use (at the top of a patch, or one pixel group ahead): issued where it is needed, the load's full memory
+// latency is exposed once per patch, and these kernels do not have the occupancy to cover it.
+template <typename T>
+__device__ __forceinline__ void dw_epilogue_store_pre(const DwParams& p, unsigned idx, const f22& v, const f22& yv,
+                                                      const f22& es, const f22& eh, const f22& em, const f22& er, f22& s,
+                                                      f22& q) {
+    T* y = reinterpret_cast<T*>(p.y);
+    f22 g;
+    g.lo = v.lo * silu_grad2(yv.lo * es.lo + eh.lo);
+    g.hi = v.hi * silu_grad2(yv.hi * es.hi + eh.hi);
+    s.lo += g.lo; s.hi += g.hi;
+    q.lo += g.lo * ((yv.lo - em.lo) * er.lo);
+    q.hi += g.hi * ((yv.hi - em.hi) * er.hi);
+    store22<T>(y + idx, g);
+}
+
 // block-level reduction of per-thread (s, q) over the pixel-threads that share a channel vector
 __device__ __forceinline__ void dw_write_stats(const DwParams& p, float* red, int tid, int nvec, int npt, int c0,
                                                int cbv, const f22& s, const f22& q, int slot) {
@@ -206,7 +223,7 @@ constexpr int DW_NV = 16;   // pixels per thread in a staged input tile (forward
 constexpr int DW_NVX = 12;  // weight-gradient kernel: input tile
 constexpr int DW_NVD = 8;   //                          output-gradient tile
 
-template <typename T, int K, int S, int PH>
+template <typename T, int K, int S, int PH, bool EPI>   // EPI: p.yfwd != nullptr (the data gradient's fused epilogue)
 __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
     constexpr int PAD = (K - 1) / 2;
     constexpr int NIN = (DW_PW - 1) * S + K;   // staged input pixels per patch row
@@ -279,6 +296,24 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
             int ph = ptc / patches_w, pw = ptc - ph * patches_w;
             for (int patch = ptc; patch < npatch; patch += npt) {
                 const int ohl = ph * PH, owl = pw * DW_PW;
+                // the epilogue's operand, requested before the taps are computed (addresses clamped into the image so
+                // that the loads need no branches; the stores below keep their edge tests)
+                typename Raw4T<T>::type yraw[EPI ? PH : 1][DW_PW];
+                if constexpr (EPI) {
+                    const T* yimg = reinterpret_cast<const T*>(p.yfwd) + (size_t)b * p.OH * p.OW * p.C + c;
+#pragma unroll
+                    for (int a = 0; a < PH; ++a) {
+                        int oh = oh0 + ohl + a;
+                        oh = oh < p.OH ? oh : p.OH - 1;
+#pragma unroll
+                        for (int q_ = 0; q_ < DW_PW; ++q_) {
+                            int ow = ow0 + owl + q_;
+                            ow = ow < p.OW ? ow : p.OW - 1;
+                            yraw[a][q_] = *reinterpret_cast<const typename Raw4T<T>::type*>(
+                                yimg + (unsigned)((oh * p.OW + ow) * p.C));
+                        }
+                    }
+                }
                 f22 acc[PH][DW_PW];
 #pragma unroll
                 for (int a = 0; a < PH; ++a)
@@ -315,7 +350,11 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
                             const int ow = ow0 + owl + q_;
                             if (ow < p.OW) {
                                 const unsigned idx = (unsigned)(((b * p.OH + oh) * p.OW + ow) * p.C + c);
-                                dw_epilogue_store<T>(p, idx, acc[a][q_], es, eh, em, er, st_s, st_q);
+                                if constexpr (EPI)
+                                    dw_epilogue_store_pre<T>(p, idx, acc[a][q_], Raw4T<T>::unpack22(yraw[a][q_]), es, eh,
+                                                             em, er, st_s, st_q);
+                                else
+                                    dw_epilogue_store<T>(p, idx, acc[a][q_], es, eh, em, er, st_s, st_q);
                             }
                         }
                     }
@@ -569,6 +608,22 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_s2_kernel(DwParams p) {
             int ph = ptc / patches_w, pw = ptc - ph * patches_w;
             for (int patch = ptc; patch < npatch; patch += npt) {
                 const int rl = ph, ql = pw * 2;   // first cell of the patch, tile-local
+                typename Raw4T<T>::type yraw[2][4];   // the epilogue's operand, requested ahead of the tap arithmetic
+                if (p.yfwd) {
+                    const T* yimg = reinterpret_cast<const T*>(p.yfwd) + (size_t)b * p.H * p.W * p.C + c;
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        int ih = (r0 + rl) * 2 + pr;
+                        ih = ih < p.H ? ih : p.H - 1;
+#pragma unroll
+                        for (int x_ = 0; x_ < 4; ++x_) {
+                            int iw = (q0 + ql) * 2 + x_;
+                            iw = iw < p.W ? iw : p.W - 1;
+                            yraw[pr][x_] = *reinterpret_cast<const typename Raw4T<T>::type*>(
+                                yimg + (unsigned)((ih * p.W + iw) * p.C));
+                        }
+                    }
+                }
                 // dY window of the patch: rows rl-1..rl+1, cols ql-1..ql+2 (tile-local + 1 for the halo)
                 f22 in[3][4];
 #pragma unroll
@@ -604,7 +659,11 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_s2_kernel(DwParams p) {
                             const int iw = (q0 + ql) * 2 + x_;
                             if (iw < p.W) {
                                 const unsigned idx = (unsigned)(((b * p.H + ih) * p.W + iw) * p.C + c);
-                                dw_epilogue_store<T>(p, idx, acc[pr][x_], es, eh, em, er, st_s, st_q);
+                                if (p.yfwd)
+                                    dw_epilogue_store_pre<T>(p, idx, acc[pr][x_], Raw4T<T>::unpack22(yraw[pr][x_]), es,
+                                                             eh, em, er, st_s, st_q);
+                                else
+                                    dw_epilogue_store<T>(p, idx, acc[pr][x_], es, eh, em, er, st_s, st_q);
                             }
                         }
                     }
@@ -1208,7 +1267,8 @@ static void launch_tile(const DwParams& p, int grid_x, hipStream_t s) {
     DwParams q = p;
     q.gx = grid_x; q.ncb = cdiv(p.C, p.CB);
     dim3 grid((unsigned)(q.gx * q.ncb));
-    MIA_LAUNCH((dwconv_tile_kernel<T, K, S, PH>), grid, dim3(256), lds, s, q);
+    if (p.yfwd) MIA_LAUNCH((dwconv_tile_kernel<T, K, S, PH, true>), grid, dim3(256), lds, s, q);
+    else MIA_LAUNCH((dwconv_tile_kernel<T, K, S, PH, false>), grid, dim3(256), lds, s, q);
 }
 
 template <typename T>
