@@ -38,7 +38,11 @@ long long mia_launch_count(void);
  *      nn.Linear in the heads (src/model.py:125-130, :138, :141, :312, :315) --------------------------------
  * C[M,N] = pro(A)[M,K] . B[N,K]^T (+bias[N]) (epi_act) (+D[M,N], leading dim ldc)
  * pro(a)[m,k] = pro_act(a*pscale[k] + pshift[k]) * gate[(m / rows_per_img)*K + k]   (each part optional)
- * stats (optional): part[part_rows][2][N] <- column sums and sums of squares of the raw accumulators. */
+ * stats (optional): part[part_rows][2][N] <- column sums and sums of squares of the raw accumulators.
+ * bf16 projections of the large maps (M >= 400 000, K <= 192, N <= 32, BatchNorm+SiLU prologue, statistics, maps of
+ * 1024 pixels and more when gated) run in a streaming kernel that keeps the weights in registers and folds the gate
+ * into them, (a*g).w = a.(g*w): the one bf16 rounding of the prologue then falls on g*w instead of on a*g. The
+ * environment variable MIA_GEMM_NO_STREAM, read once per process, keeps the tiled kernel everywhere (A/B runs). */
 int mia_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* D, int M,
                 int N, int K, const float* pscale, const float* pshift, int pro_act, const float* gate,
                 int rows_per_img, const float* bias, int epi_act, float* stats, int part_rows, void* stream);

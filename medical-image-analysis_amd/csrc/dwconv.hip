@@ -483,6 +483,9 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(DwParams p) {
         if (wave_on) {
             const int lim_h = p.OH - oh0, lim_w = p.OW - ow0;
             const unsigned out0 = (unsigned)(((b * p.OH + oh0) * p.OW + ow0) * p.C + c);
+            // (Loading the epilogue's forward value one pixel group ahead, as the tile kernels do per patch, was
+            // measured here too: 2-4 % on the data gradient, and the forward pass loses as much to the tighter
+            // register budget -- this kernel sits at an occupancy step.)
             for (int g0 = sub * 16; g0 < npos; g0 += 16 * WPG) {
                 const int4 pe = ptab[g0 + pix_l];
                 const T* bp = reinterpret_cast<const T*>(reinterpret_cast<const char*>(tile) + pe.x) + cl;

@@ -600,6 +600,252 @@ static int launch_nt_(const GemmNTParams& p, int part_rows, hipStream_t stream) 
     return 0;
 }
 
+// ================================================================================================
+// Streaming form of gemm_nt for the projections of the large maps (bf16, BatchNorm+SiLU(+gate) prologue, column
+// statistics): few channels on both sides, millions of rows. There the whole weight matrix is a handful of MFMA
+// operands, so every wave keeps it in REGISTERS for the whole kernel and streams rows past it: no LDS staging, no
+// barriers, no tiles shared between waves (the tiled kernel spends these launches in its commit/barrier cycle: 2.2-3.3
+// TB/s where this form reaches 3.6-4.3). The product is computed transposed, D[n][m] = W[n][:] . act[m][:], with the
+// weights as the first MFMA operand: a lane then
+//   - supplies activations as 16-byte global loads already in operand layout (lane = m + 16*g holds 8 consecutive k
+//     of row m) and runs the prologue on those registers,
+//   - receives four consecutive output channels of ONE row: an 8-byte store straight from the accumulator.
+// The squeeze-excite gate multiplies the WEIGHTS instead of the activations, (a*g).w = a.(g*w): a wave walks a
+// contiguous range of 16-row blocks image by image, blocks never cross an image, and the weight operands are re-derived
+// when the range enters the next image (once in hundreds of blocks). Rounding therefore happens on g*w instead of on
+// a*g: one bf16 rounding either way.
+// Loads run two blocks ahead of the arithmetic; all loads and stores of the inner loop are unconditional buffer
+// accesses (masked through out-of-range offsets), so its waits are counted ones that leave the younger requests in
+// flight. Column statistics: per-lane sums, folded once per workgroup in a fixed order (one row of partials each).
+// (The same kernel without prologue was measured on the expansions and data gradients of these maps: the 8-byte
+// stores lose to the tiled kernel's 16-byte row chunks wherever the output is the wide side -- 128 vs 67 us on the
+// 192-channel data gradient -- and without the prologue's arithmetic to hide there is nothing to gain on the rest.)
+// ================================================================================================
+template <int NTW, int KS, int MT>
+__global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(GemmNTParams p) {
+    typedef bf16_t T;
+    constexpr bool PS_LDS = KS > 2;     // BatchNorm vectors from LDS (too many k slots per lane for registers)
+    constexpr int KP = KS * 32;
+    __shared__ float Ps[PS_LDS ? 2 * KP : 4];
+    __shared__ float red[4 * 2 * NTW * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ml = lane & 15, g = lane >> 4;
+    const int M = p.M, N = p.N, K = p.K;
+    // BatchNorm + SiLU on the activations is fixed at compile time (a run-time choice of the activation inside the
+    // loop makes the compiler wait for every load in flight before the first use); the gate is optional
+    const bool has_gate = p.gate != nullptr;
+    const int rpi = has_gate ? p.rows_per_img : M;           // blocks never cross an image (one "image" without a gate)
+    const int nimg = (M + rpi - 1) / rpi;
+    constexpr int RB = 16 * MT;                              // rows per block
+    const int bpi = (rpi + RB - 1) / RB;
+    const int total = nimg * bpi;
+    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const int per = (total + nw - 1) / nw;
+    const int blk0 = gw * per;
+    const int blk_end = blk0 + per < total ? blk0 + per : total;
+
+    int kb[KS];       // first k of (MFMA step s, lane group g)
+    bool kok[KS];
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_) {
+        kb[s_] = s_ * 32 + g * 8;
+        kok[s_] = kb[s_] < K;
+    }
+    if constexpr (PS_LDS) {
+        for (int i = tid; i < KP; i += 256) {
+            Ps[i] = i < K ? p.pscale[i] : 0.f;
+            Ps[KP + i] = i < K ? p.pshift[i] : 0.f;
+        }
+        __syncthreads();
+    }
+    float psc[!PS_LDS ? KS : 1][8], psh[!PS_LDS ? KS : 1][8];
+    if constexpr (!PS_LDS) {
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                psc[s_][e] = kok[s_] ? p.pscale[kb[s_] + e] : 0.f;
+                psh[s_][e] = kok[s_] ? p.pshift[kb[s_] + e] : 0.f;
+            }
+    }
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, (unsigned)(((size_t)(M - 1) * p.lda + K) * sizeof(T)));
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.B, (unsigned)(((size_t)(N - 1) * p.ldb + K) * sizeof(T)));
+    const __amdgpu_buffer_rsrc_t rsC = make_rsrc(p.C, (unsigned)(((size_t)(M - 1) * p.ldc + N) * sizeof(T)));
+    const __amdgpu_buffer_rsrc_t rsG = make_rsrc(p.gate, has_gate ? (unsigned)((size_t)nimg * K * 4) : 0u);
+
+    // weight operands: lane (ml, g) holds W[nt*16 + ml][kb[s] .. +7], times the image's gate
+    bf16x8v wf[NTW][KS];
+    auto load_w = [&](int img) {
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            float gt[8];
+            if (has_gate) {
+                const unsigned goff = kok[s_] ? (unsigned)(img * K + kb[s_]) * 4u : MIA_BUF_OOB;
+                const raw16 g0 = buf_load16<false>(rsG, goff), g1 = buf_load16<false>(rsG, goff == MIA_BUF_OOB ? goff : goff + 16u);
+                gt[0] = __uint_as_float(g0.x); gt[1] = __uint_as_float(g0.y); gt[2] = __uint_as_float(g0.z); gt[3] = __uint_as_float(g0.w);
+                gt[4] = __uint_as_float(g1.x); gt[5] = __uint_as_float(g1.y); gt[6] = __uint_as_float(g1.z); gt[7] = __uint_as_float(g1.w);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int n = nt * 16 + ml;
+                const unsigned off = (n < N && kok[s_]) ? (unsigned)(n * p.ldb + kb[s_]) * 2u : MIA_BUF_OOB;
+                raw16 w = buf_load16<false>(rsW, off);
+                if (has_gate) w = Pro16<T>::template apply<false, false, true>(w, nullptr, nullptr, gt);
+                wf[nt][s_] = __builtin_bit_cast(bf16x8v, w);
+            }
+        }
+    };
+
+    struct Frag {
+        raw16 a[MT][KS];
+    };
+    // A wave's range is walked image by image (a "segment" = its blocks inside one image): the weight operands are
+    // fixed inside a segment, and the inner loop holds nothing but counted loads, arithmetic and stores.
+    int seg_end = 0, row0 = 0, bi_base = 0;   // current segment: end block, first row and first block of its image
+    auto fetch = [&](Frag& f, int blk) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int r = ((blk - bi_base) * MT + t) * 16 + ml;
+            const int m = row0 + r;
+            const bool ok = blk < seg_end && r < rpi && m < M;
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_)
+                f.a[t][s_] = buf_load16<true>(rsA, (ok && kok[s_]) ? (unsigned)(m * p.lda + kb[s_]) * 2u : MIA_BUF_OOB);
+        }
+    };
+
+    float st_s[NTW][4], st_q[NTW][4];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st_s[nt][r] = st_q[nt][r] = 0.f;
+
+    auto process = [&](const Frag& f, int blk) {
+        // the BatchNorm vectors are re-read from LDS for every block: hoisted out of the loop (they do not change)
+        // they would occupy 16 registers per k step and push the kernel into scratch memory
+        int ps_off = 0;
+        asm volatile("" : "+v"(ps_off));
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int r = ((blk - bi_base) * MT + t) * 16 + ml;
+            const int m = row0 + r;
+            const bool ok = r < rpi && m < M;
+            bf16x8v af[KS];
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) {
+                raw16 a = f.a[t][s_];
+                if constexpr (PS_LDS) {
+                    float sc[8], sh[8];
+                    const float* ps = Ps + ps_off + kb[s_];
+                    const float4 a0 = *reinterpret_cast<const float4*>(ps);
+                    const float4 a1 = *reinterpret_cast<const float4*>(ps + 4);
+                    const float4 b0 = *reinterpret_cast<const float4*>(ps + KP);
+                    const float4 b1 = *reinterpret_cast<const float4*>(ps + KP + 4);
+                    sc[0] = a0.x; sc[1] = a0.y; sc[2] = a0.z; sc[3] = a0.w; sc[4] = a1.x; sc[5] = a1.y; sc[6] = a1.z; sc[7] = a1.w;
+                    sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
+                    a = Pro16<T>::template apply<true, true, false>(a, sc, sh, nullptr);
+                } else {
+                    a = Pro16<T>::template apply<true, true, false>(a, psc[s_], psh[s_], nullptr);
+                }
+                // rows outside the block contribute nothing (their loads returned zeros, but silu(shift) != 0)
+                if (!ok) a = make_uint4(0u, 0u, 0u, 0u);
+                af[s_] = __builtin_bit_cast(bf16x8v, a);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][s_], af[s_], acc, 0, 0, 0);
+                // this lane: row m, channels nt*16 + 4g .. +3
+#pragma unroll
+                for (int r_ = 0; r_ < 4; ++r_) {
+                    st_s[nt][r_] += acc[r_];
+                    st_q[nt][r_] += acc[r_] * acc[r_];
+                }
+                const int n = nt * 16 + g * 4;
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                const v2u o = {pack_bf16x2(v2f{acc[0], acc[1]}), pack_bf16x2(v2f{acc[2], acc[3]})};
+                __builtin_amdgcn_raw_buffer_store_b64(o, rsC, (ok && n < N) ? (unsigned)(m * p.ldc + n) * 2u : MIA_BUF_OOB, 0, 0);
+            }
+        }
+    };
+    // Three register sets in rotation, by name: a copy between sets would have to wait for the loads it copies.
+    Frag f0, f1, f2;
+    for (int seg = blk0; seg < blk_end; seg = seg_end) {
+        const int img = seg / bpi;
+        bi_base = img * bpi;
+        row0 = img * rpi;
+        seg_end = bi_base + bpi < blk_end ? bi_base + bpi : blk_end;
+        load_w(img);
+        fetch(f0, seg);
+        fetch(f1, seg + 1);
+        // three blocks per turn; the first turn is peeled off so that the loop is entered with the same requests in
+        // flight as its back edge has
+        auto turn = [&](int blk) -> bool {
+            fetch(f2, blk + 2);
+            process(f0, blk);
+            if (blk + 1 >= seg_end) return false;
+            fetch(f0, blk + 3);
+            process(f1, blk + 1);
+            if (blk + 2 >= seg_end) return false;
+            fetch(f1, blk + 4);
+            process(f2, blk + 2);
+            return blk + 3 < seg_end;
+        };
+        int blk = seg;
+        if (turn(blk)) {
+            blk += 3;
+            while (turn(blk)) blk += 3;
+        }
+    }
+    // lanes ml = 0..15 of a group g hold the same channels: fold them, then the waves of the workgroup in order
+    float* mine = red + wave * 2 * NTW * 16;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int r_ = 0; r_ < 4; ++r_) {
+            float a = st_s[nt][r_], b = st_q[nt][r_];
+            a += dpp_f32<MIA_DPP_QUAD_XOR1>(a); b += dpp_f32<MIA_DPP_QUAD_XOR1>(b);
+            a += dpp_f32<MIA_DPP_QUAD_XOR2>(a); b += dpp_f32<MIA_DPP_QUAD_XOR2>(b);
+            a += dpp_f32<MIA_DPP_ROW_HALF_MIRROR>(a); b += dpp_f32<MIA_DPP_ROW_HALF_MIRROR>(b);
+            a += dpp_f32<MIA_DPP_ROW_MIRROR>(a); b += dpp_f32<MIA_DPP_ROW_MIRROR>(b);
+            if (ml == 0) {
+                mine[nt * 16 + g * 4 + r_] = a;
+                mine[NTW * 16 + nt * 16 + g * 4 + r_] = b;
+            }
+        }
+    __syncthreads();
+    if (tid < NTW * 16 && tid < N) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            a += red[w * 2 * NTW * 16 + tid];
+            b += red[w * 2 * NTW * 16 + NTW * 16 + tid];
+        }
+        p.stats[((size_t)blockIdx.x * 2 + 0) * N + tid] = a;
+        p.stats[((size_t)blockIdx.x * 2 + 1) * N + tid] = b;
+    }
+}
+
+// Shapes the streaming kernel is built for (the 24- and 32-channel projections of the 150x150 and 75x75 maps), and
+// its launch. Returns 1 when it took the product.
+static int try_skinny(const GemmNTParams& p, int part_rows, hipStream_t stream) {
+    static const bool off = getenv("MIA_GEMM_NO_STREAM") != nullptr;   // documented A/B switch, read once per process
+    if (off) return 0;
+    if (!p.pscale || p.pro_act != MIA_ACT_SILU || !p.stats || p.bias || p.D || p.epi_act != MIA_ACT_NONE) return 0;
+    if (p.M < 400000 || p.N % 4 || p.ldc % 4 || p.K % 8 || p.K > 192 || p.N > 32 || part_rows < 64) return 0;
+    if (p.gate && (p.rows_per_img < 1024 || p.M % p.rows_per_img)) return 0;
+    const dim3 grid((unsigned)part_rows);
+    switch (cdiv(p.K, 32)) {
+        case 1: MIA_LAUNCH((gemm_skinny_kernel<2, 1, 2>), grid, dim3(256), 0, stream, p); return 1;
+        case 2: MIA_LAUNCH((gemm_skinny_kernel<2, 2, 2>), grid, dim3(256), 0, stream, p); return 1;
+        case 5: MIA_LAUNCH((gemm_skinny_kernel<2, 5, 1>), grid, dim3(256), 0, stream, p); return 1;
+        case 6: MIA_LAUNCH((gemm_skinny_kernel<2, 6, 1>), grid, dim3(256), 0, stream, p); return 1;
+        default: return 0;
+    }
+}
+
 // Column-tile widths on offer (multiples of 16). 144 = 6*24 divides most EfficientNet-B3 expanded widths.
 template <typename T>
 static int dispatch_nt(const GemmNTParams& p, int part_rows, hipStream_t stream) {
@@ -661,8 +907,11 @@ extern "C" int mia_gemm_nt(int dtype, const void* A, int lda, const void* B, int
     p.pscale = pscale; p.pshift = pshift; p.gate = gate; p.rows_per_img = rows_per_img > 0 ? rows_per_img : 1;
     p.pro_act = pro_act; p.bias = bias; p.epi_act = epi_act; p.stats = stats;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MIA_BF16) dispatch_nt<bf16_t>(p, part_rows, s);
-    else dispatch_nt<float>(p, part_rows, s);
+    if (dtype == MIA_BF16) {
+        if (!try_skinny(p, part_rows, s)) dispatch_nt<bf16_t>(p, part_rows, s);
+    } else {
+        dispatch_nt<float>(p, part_rows, s);
+    }
     MIA_CHECK_LAUNCH("mia_gemm_nt");
     return 0;
 }

@@ -106,6 +106,21 @@ def gemm_case(M, N, K, pro, stats, act=None, use_gate=True):
             kw.update(gate=gate)
     return (lambda: ops.gemm_nt(a, b, **kw)), nbytes
 
+def gemm_add_case(M, N, K, add):
+    """Data gradient of an expansion convolution: [M,K] x [N,K]^T (+ the residual's gradient)."""
+    a, b = rnd(M, K), rnd(N, K)
+    d = rnd(M, N) if add else None
+    nbytes = (M * K + N * K + M * N * (2 if add else 1)) * 2
+    return (lambda: ops.gemm_nt(a, b, add=d)), nbytes
+
+for nm, (hw_, n_, k_) in {"1": (75 * 75, 32, 192), "2": (38 * 38, 48, 288), "3": (19 * 19, 96, 576),
+                          "4": (19 * 19, 136, 816), "5": (100, 232, 1392), "6": (100, 384, 2304)}.items():
+    CASES[f"gemm_dx{nm}"] = (lambda h=hw_, n=n_, k=k_: gemm_add_case(B * h, n, k, True))
+    CASES[f"gemm_dx{nm}_noadd"] = (lambda h=hw_, n=n_, k=k_: gemm_add_case(B * h, n, k, False))
+
+CASES["gemm_proj00"] = lambda: gemm_case(B * 150 * 150, 24, 40, True, True)
+CASES["gemm_proj01"] = lambda: gemm_case(B * 150 * 150, 24, 24, True, True)
+CASES["gemm_proj21"] = lambda: gemm_case(B * 38 * 38, 48, 288, True, True)
 CASES["gemm_exp10"] = lambda: gemm_case(B * 150 * 150, 144, 24, False, True)
 CASES["gemm_exp11"] = lambda: gemm_case(B * 75 * 75, 192, 32, False, True)
 CASES["gemm_proj11"] = lambda: gemm_case(B * 75 * 75, 32, 192, True, True)

@@ -46,7 +46,12 @@ def test_gemm_nt_plain(dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K,hw", [(2 * 361, 136, 816, 361), (3 * 100, 32, 192, 100), (4 * 49, 384, 2304, 49)])
+@pytest.mark.parametrize("M,N,K,hw", [(2 * 361, 136, 816, 361), (3 * 100, 32, 192, 100), (4 * 49, 384, 2304, 49),
+                                      # maps of 1024 pixels and more take the prologue form that keeps one gate vector
+                                      # per tile: tiles that lie in one image, tiles that straddle two (1500 and 1100
+                                      # are no multiples of the 128-row tile), several k stages (K = 192, 288)
+                                      (3 * 1500, 24, 40, 1500), (4 * 1100, 32, 192, 1100), (2 * 1444, 48, 288, 1444),
+                                      (5 * 1024, 24, 24, 1024)])
 def test_gemm_nt_prologue_gate_stats(dtype, M, N, K, hw):
     a, b = rnd(M, K, seed=1, dtype=dtype), rnd(N, K, seed=2, scale=K ** -0.5, dtype=dtype)
     sc, sh = rnd(K, seed=3).abs() + 0.5, rnd(K, seed=4, scale=0.3)
@@ -75,6 +80,38 @@ def test_gemm_nt_plain_tall(M, N, K):
     assert relerr(out.float(), ref) < tol(torch.bfloat16)
     out, _ = ops.gemm_nt(a, b, add=d)
     assert relerr(out.float(), ref + d.float()) < tol(torch.bfloat16)
+
+
+# The streaming kernel of the large-map projections (400 000 rows and more, at most 192 -> 32 channels): the shapes of
+# EfficientNet-B3's first two stages at a batch that reaches the row threshold; images whose row count is no multiple
+# of the 16- or 32-row blocks, a row count that is not a multiple of the image size of the last case's ranges.
+STREAM_PRO = [(20, 22500, 24, 40), (20, 22500, 24, 24), (72, 5625, 32, 144), (72, 5625, 32, 192), (400, 1024, 24, 40),
+              (401, 1027, 28, 160)]
+
+
+@pytest.mark.parametrize("B,hw,N,K", STREAM_PRO)
+def test_gemm_nt_streaming_prologue_gate_stats(B, hw, N, K):
+    M = B * hw
+    a, b = rnd(M, K, seed=1, dtype=torch.bfloat16), rnd(N, K, seed=2, scale=K ** -0.5, dtype=torch.bfloat16)
+    sc, sh = rnd(K, seed=3).abs() + 0.5, rnd(K, seed=4, scale=0.3)
+    gate = torch.sigmoid(rnd(B, K, seed=5))
+    out, part = ops.gemm_nt(a, b, pscale=sc, pshift=sh, pro_act=ops.ACT_SILU, gate=gate, rows_per_img=hw,
+                            stats_rows=512)
+    ap = F.silu(a.float() * sc + sh) * gate.repeat_interleave(hw, 0)
+    ref = ap @ b.float().t()
+    assert relerr(out.float(), ref) < 2e-2
+    s = part.sum(0)
+    assert relerr(s[0], ref.sum(0)) < 2e-3
+    assert relerr(s[1], (ref * ref).sum(0)) < 2e-3
+    # every image gets ITS gate: a wrong image index at a block boundary shows as a per-image error
+    err = (out.float() - ref).view(B, hw, N).abs().amax((1, 2)) / ref.abs().max()
+    assert err.max().item() < 2e-2
+    # without a gate (one "image" of M rows); repeated launches agree bit for bit (fixed summation order)
+    outs = [ops.gemm_nt(a, b, pscale=sc, pshift=sh, pro_act=ops.ACT_SILU, stats_rows=384) for _ in range(3)]
+    ref2 = F.silu(a.float() * sc + sh) @ b.float().t()
+    assert relerr(outs[0][0].float(), ref2) < 2e-2
+    assert relerr(outs[0][1].sum(0)[1], (ref2 * ref2).sum(0)) < 2e-3
+    assert all(torch.equal(o[1], outs[0][1]) and torch.equal(o[0], outs[0][0]) for o in outs[1:])
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
