@@ -185,6 +185,19 @@ for mode in ("fwd", "bwd"):
     CASES[f"se{mode}_s3"] = (lambda m=mode: se_case(576, 24, 361, m))
     CASES[f"se{mode}_s2"] = (lambda m=mode: se_case(288, 12, 1444, m))
 
+def bnfin_case(C, P, mode):
+    part = torch.randn(P, 2, C, device="cuda").abs()
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    st = ops.bn_finalize_fwd(part, 1000.0, ops.BNState(bn))
+    nbytes = part.numel() * 4
+    if mode == "fwd":
+        return (lambda: ops.bn_finalize_fwd(part, 1000.0, ops.BNState(bn))), nbytes
+    return (lambda: ops.bn_finalize_bwd(part, 1000, bn.weight, st, True)), nbytes
+
+for mode in ("fwd", "bwd"):
+    for C_, P_ in ((32, 512), (192, 512), (816, 512), (2304, 400)):
+        CASES[f"bnfin{mode}_{C_}"] = (lambda c=C_, p_=P_, m=mode: bnfin_case(c, p_, m))
+
 def _fill_case():
     x = torch.empty(512 * 1024 * 1024, dtype=torch.bfloat16, device="cuda")
     return (lambda: x.zero_()), x.numel() * 2
