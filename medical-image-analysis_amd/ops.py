@@ -27,6 +27,18 @@ def _p(t: Optional[torch.Tensor]):
     return t.data_ptr()     # a plain int: the prototypes declare void*, ctypes converts without a wrapper object
 
 
+def _pr(t, i: int):
+    """Device pointer of row i of a 2-D tensor whose rows are contiguous (the BatchNorm state and coefficient tables):
+    the address is computed, no view tensor is built. A row view costs about a microsecond of host time, and these
+    rows are handed to kernels some 1300 times a step."""
+    if not isinstance(t, torch.Tensor):
+        return _p(t[i])           # a tuple / list of row tensors
+    if not t.is_cuda:
+        raise RuntimeError("mia_amd kernels need tensors on an MI355X device; there is no CPU path "
+                           f"(got a {t.device} tensor of shape {tuple(t.shape)})")
+    return t.data_ptr() + i * t.stride(0) * t.element_size()
+
+
 # torch.cuda.current_stream() builds a Stream object through several Python layers (~8 us a call, once per kernel
 # launch: half of a step's host time); the raw handle is one C call away
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -330,8 +342,8 @@ def dwconv_bwd_data_lin(dy, w, k, s, x, *, yfwd, st, gamma, wexp, stats_rows):
     dxp = torch.empty((B * H * W, Cin), dtype=dy.dtype, device=dev)
     t1 = torch.empty((C, Cin), dtype=torch.float32, device=dev)
     _launch("dwconv_bwd_data_lin", (dy.numel() + yfwd.numel() + 2 * x.numel()) * dy.element_size(),
-            lib().mia_dwconv_bwd_data_lin, _DT[dy.dtype], _p(dy), B, H, W, C, _p(w), k, s, _p(yfwd), _p(st[0]), _p(st[1]),
-            _p(st[2]), _p(st[3]), _p(gamma), _p(wexp), _p(x), Cin, _p(dxp), _p(t1), _p(part), rows, _p(ws), ws.numel(),
+            lib().mia_dwconv_bwd_data_lin, _DT[dy.dtype], _p(dy), B, H, W, C, _p(w), k, s, _p(yfwd), _pr(st, 0), _pr(st, 1),
+            _pr(st, 2), _pr(st, 3), _p(gamma), _p(wexp), _p(x), Cin, _p(dxp), _p(t1), _p(part), rows, _p(ws), ws.numel(),
             _stream())
     return dxp, t1, part
 
@@ -367,7 +379,7 @@ def bn_finalize_fwd(part, count, bn: BNState, conv_bias=None):
         WeightEpoch.bump()      # the kernel updates the running statistics in place
     lib().mia_bn_finalize_fwd(_p(part), P, C, float(count), _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
                               _p(bn.running_var), _p(bn.nbt), float(bn.momentum), float(bn.eps),
-                              1 if bn.training else 0, _p(conv_bias), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]),
+                              1 if bn.training else 0, _p(conv_bias), _pr(out, 0), _pr(out, 1), _pr(out, 2), _pr(out, 3),
                               _stream())
     return out  # rows: scale, shift, mean, rstd
 
@@ -375,9 +387,9 @@ def bn_finalize_fwd(part, count, bn: BNState, conv_bias=None):
 def bn_finalize_bwd(part, count, gamma, stats, training):
     C = gamma.shape[0]
     coef = torch.empty((6, C), dtype=torch.float32, device=gamma.device)  # dgamma, dbeta, ca, cb, cd, dconv_bias
-    lib().mia_bn_finalize_bwd(_p(part), part.shape[0], C, float(count), _p(gamma), _p(stats[2]), _p(stats[3]),
-                              1 if training else 0, _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _p(coef[4]),
-                              _p(coef[5]), _stream())
+    lib().mia_bn_finalize_bwd(_p(part), part.shape[0], C, float(count), _p(gamma), _pr(stats, 2), _pr(stats, 3),
+                              1 if training else 0, _pr(coef, 0), _pr(coef, 1), _pr(coef, 2), _pr(coef, 3), _pr(coef, 4),
+                              _pr(coef, 5), _stream())
     return coef
 
 
@@ -395,8 +407,8 @@ def bn_act_bwd_reduce(g, y, stats, act, *, gate=None, dpool=None, rows_per_img=0
     elif out is None:
         out = torch.empty_like(g)
     _launch("bn_act_bwd_reduce", g.numel() * g.element_size() * (3 if writes else 2), lib().mia_bn_act_bwd_reduce,
-            _DT[g.dtype], _p(g), _p(out) if writes else None, _p(y), R, C, _p(stats[0]), _p(stats[1]), _p(stats[2]),
-            _p(stats[3]), act, _p(gate), _p(dpool), rows_per_img, _p(part), rows, _stream())
+            _DT[g.dtype], _p(g), _p(out) if writes else None, _p(y), R, C, _pr(stats, 0), _pr(stats, 1), _pr(stats, 2),
+            _pr(stats, 3), act, _p(gate), _p(dpool), rows_per_img, _p(part), rows, _stream())
     return out, part
 
 
@@ -440,7 +452,7 @@ def se_bwd_sums(y, dz, stats, gate=None):
     out = torch.empty((5, B, splits, C), dtype=torch.float32, device=y.device)
     pre = gate is not None and splits == 1
     _launch("se_bwd_sums", y.numel() * y.element_size() * 2, lib().mia_se_bwd_sums, _DT[y.dtype], _p(y), _p(dz), B, HW,
-            C, _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), splits, _p(out), _p(gate) if pre else None,
+            C, _pr(stats, 0), _pr(stats, 1), _pr(stats, 2), _pr(stats, 3), splits, _p(out), _p(gate) if pre else None,
             _stream())
     out.pre_scaled = pre
     return out
@@ -458,8 +470,8 @@ def bn_act_bwd_apply(g, y, stats, act, coef, *, gate=None, dpool=None, rows_per_
     C = g.shape[-1]
     R = g.numel() // C
     _launch("bn_act_bwd_apply", g.numel() * g.element_size() * 3, lib().mia_bn_act_bwd_apply, _DT[g.dtype], _p(g), _p(y),
-            R, C, _p(stats[0]), _p(stats[1]), act, _p(gate), _p(dpool), rows_per_img, _p(coef[2]), _p(coef[3]),
-            _p(coef[4]), _stream())
+            R, C, _pr(stats, 0), _pr(stats, 1), act, _p(gate), _p(dpool), rows_per_img, _pr(coef, 2), _pr(coef, 3),
+            _pr(coef, 4), _stream())
     return g
 
 
@@ -508,7 +520,7 @@ def bn_lin_prep(w, coef):
     wcaT = torch.empty((Cin, Cm), dtype=w.dtype, device=w.device)
     S = torch.empty((Cin, Cin), dtype=w.dtype, device=w.device)
     r = torch.empty((Cin,), dtype=torch.float32, device=w.device)
-    lib().mia_bn_lin_prep(_DT[w.dtype], _p(w), Cm, Cin, _p(coef[2]), _p(coef[3]), _p(coef[4]), _p(wcaT), _p(S), _p(r),
+    lib().mia_bn_lin_prep(_DT[w.dtype], _p(w), Cm, Cin, _pr(coef, 2), _pr(coef, 3), _pr(coef, 4), _p(wcaT), _p(S), _p(r),
                           _stream())
     return wcaT, S, r
 
@@ -516,7 +528,7 @@ def bn_lin_prep(w, coef):
 def bn_lin_fix(t1, w, coef, G, cs):
     """In place on t1 = g^T x [Cm,Cin] fp32 -> the weight gradient of the convolution in front of the BatchNorm."""
     Cm, Cin = w.shape
-    lib().mia_bn_lin_fix(_DT[w.dtype], _p(w), Cm, Cin, _p(coef[2]), _p(coef[3]), _p(coef[4]), _p(G), _p(cs), _p(t1),
+    lib().mia_bn_lin_fix(_DT[w.dtype], _p(w), Cm, Cin, _pr(coef, 2), _pr(coef, 3), _pr(coef, 4), _p(G), _p(cs), _p(t1),
                          _stream())
     return t1
 

@@ -31,6 +31,30 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.mia_last_error() is not None
 
 
+def test_fast_call_binding_matches_the_ctypes_binding():
+    """The generated fast-call module is bound to the same loaded library and behaves like the ctypes prototypes:
+    same return values, same exception type and message for a refused call, argument count checked."""
+    lib = mia_amd.lib()
+    assert lib.fastcall, "build.py's build_fast() output is missing or was generated from other prototypes"
+    from mia_amd import _mia_fast, _proto
+    assert _mia_fast.digest() == _proto.header_digest()
+    assert lib.mia_version is _mia_fast.mia_version
+    assert lib.mia_version() == lib._dll.mia_version()
+    assert lib.mia_dwconv_bwd_data_lin_supported(1, 144, 3, 2, 24) == 1
+    assert lib.mia_dwconv_bwd_data_lin_supported(0, 144, 3, 2, 24) == 0
+    assert lib.mia_gemm_tn_ws_floats(1, 100000, 144, 24, 0) == lib._dll.mia_gemm_tn_ws_floats(1, 100000, 144, 24, 0)
+    with pytest.raises(mia_amd.MiaError, match=r"mia_gemm_nt failed \(-1\): .*bad dtype"):
+        lib.mia_gemm_nt(7, None, 0, None, 0, None, 0, None, 1, 1, 1, None, None, 0, None, 0, None, 0, None, 0, None)
+    with pytest.raises(TypeError, match="takes 21 arguments"):
+        lib.mia_gemm_nt(7, None)
+    with pytest.raises(TypeError):
+        lib.mia_gemm_nt("x", None, 0, None, 0, None, 0, None, 1, 1, 1, None, None, 0, None, 0, None, 0, None, 0, None)
+    # addresses: ints, None, ctypes pointer objects and ctypes arrays
+    arr = (ctypes.c_float * 3)(1.0, 2.0, 3.0)
+    with pytest.raises(mia_amd.MiaError, match="channels must be 1 or 3"):
+        lib.mia_resize_normalize_u8(16, 1, 4, 4, 2, ctypes.c_void_p(16), 4, 4, arr, ctypes.cast(arr, ctypes.c_void_p), 1, None)
+
+
 def test_header_cites_reference_for_every_entry_point_group():
     text = open(os.path.join(ROOT, "include", "mia_hip.h")).read()
     for cite in ("src/model.py:283-288", "src/model.py:28-108", "model.py:153-163", "src/loss.py:147",
