@@ -220,10 +220,14 @@ __device__ __forceinline__ void dw_decode_block(const DwParams& p, int& slot, in
 }
 
 constexpr int DW_NV = 16;   // pixels per thread in a staged input tile (forward / data-gradient kernel)
+
 constexpr int DW_NVX = 12;  // weight-gradient kernel: input tile
 constexpr int DW_NVD = 8;   //                          output-gradient tile
 
-template <typename T, int K, int S, int PH, bool EPI>   // EPI: p.yfwd != nullptr (the data gradient's fused epilogue)
+// EPI: p.yfwd != nullptr (the data gradient's fused epilogue). A compile-time choice: the forward instance then carries
+// neither the epilogue's four channel vectors nor its branch (158 -> 142 registers at 3x3 stride 1, 142 -> 126 = four
+// waves per SIMD at stride 2; forward launches 3-11 % faster). Forcing the stride-1 instance down to 128 spills.
+template <typename T, int K, int S, int PH, bool EPI>
 __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
     constexpr int PAD = (K - 1) / 2;
     constexpr int NIN = (DW_PW - 1) * S + K;   // staged input pixels per patch row
@@ -257,9 +261,11 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
     f22 psc = {v2f{1.f, 1.f}, v2f{1.f, 1.f}}, psh = zero22;
     if (has_pro && chan_ok) { psc = load22<float>(p.pscale + c); psh = load22<float>(p.pshift + c); }
     f22 es = zero22, eh = zero22, em = zero22, er = zero22;
-    if (p.yfwd && cvalid) {
-        es = load22<float>(p.escale + c); eh = load22<float>(p.eshift + c);
-        em = load22<float>(p.emean + c); er = load22<float>(p.erstd + c);
+    if constexpr (EPI) {
+        if (cvalid) {
+            es = load22<float>(p.escale + c); eh = load22<float>(p.eshift + c);
+            em = load22<float>(p.emean + c); er = load22<float>(p.erstd + c);
+        }
     }
     f22 st_s = zero22, st_q = zero22;
     __syncthreads();
@@ -353,8 +359,13 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
                                 if constexpr (EPI)
                                     dw_epilogue_store_pre<T>(p, idx, acc[a][q_], Raw4T<T>::unpack22(yraw[a][q_]), es, eh,
                                                              em, er, st_s, st_q);
-                                else
-                                    dw_epilogue_store<T>(p, idx, acc[a][q_], es, eh, em, er, st_s, st_q);
+                                else {
+                                    // no epilogue operand: the value itself and its column statistics
+                                    const f22 v = acc[a][q_];
+                                    st_s.lo += v.lo; st_s.hi += v.hi;
+                                    st_q.lo += v.lo * v.lo; st_q.hi += v.hi * v.hi;
+                                    store22<T>(reinterpret_cast<T*>(p.y) + idx, v);
+                                }
                             }
                         }
                     }
@@ -393,8 +404,8 @@ constexpr int DWM_NV = 17;    // staged pixels per thread
 // fastest on every 5x5 and 3x3 layer of the network, by 5-15 % on the 19x19 and 38x38 maps.
 constexpr int DWM_PAD = 4;
 
-template <int K, int S, int DWM_CB>
-__global__ __launch_bounds__(256) void dwconv_mfma_kernel(DwParams p) {
+template <int K, int S, int DWM_CB, bool EPI>   // EPI: p.yfwd != nullptr, as in dwconv_tile_kernel
+__global__ __launch_bounds__(256, (EPI ? (K == 5 ? 3 : 4) : 1)) void dwconv_mfma_kernel(DwParams p) {
     typedef bf16_t T;
     constexpr int PAD = (K - 1) / 2;
     constexpr int DWM_CBP = DWM_CB + DWM_PAD;   // LDS pixel stride in elements
@@ -469,9 +480,11 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(DwParams p) {
     f22 psc = {v2f{1.f, 1.f}, v2f{1.f, 1.f}}, psh = zero22;
     if (has_pro && st_ok) { psc = load22<float>(p.pscale + cst); psh = load22<float>(p.pshift + cst); }
     f22 es = zero22, eh = zero22, em = zero22, er = zero22;
-    if (p.yfwd && cvalid) {
-        es = load22<float>(p.escale + c); eh = load22<float>(p.eshift + c);
-        em = load22<float>(p.emean + c); er = load22<float>(p.erstd + c);
+    if constexpr (EPI) {
+        if (cvalid) {
+            es = load22<float>(p.escale + c); eh = load22<float>(p.eshift + c);
+            em = load22<float>(p.emean + c); er = load22<float>(p.erstd + c);
+        }
     }
     for (int wi = walk.first; wi < walk.count; wi += walk.stride) {
         const int work = walk.base + wi;
@@ -486,11 +499,26 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(DwParams p) {
         if (wave_on) {
             const int lim_h = p.OH - oh0, lim_w = p.OW - ow0;
             const unsigned out0 = (unsigned)(((b * p.OH + oh0) * p.OW + ow0) * p.C + c);
-            // (Loading the epilogue's forward value one pixel group ahead, as the tile kernels do per patch, was
-            // measured here too: 2-4 % on the data gradient, and the forward pass loses as much to the tighter
-            // register budget -- this kernel sits at an occupancy step.)
+            // Data gradient: the epilogue's forward value runs one pixel group ahead of the arithmetic. Every lane always
+            // loads (lanes without an output read element 0 of the tensor), so the loads are never under a branch and the
+            // wait before the epilogue can leave the newer request in flight. (Only in the instance with the epilogue:
+            // the forward instance must not carry these registers, it sits at an occupancy step.)
+            const T* yimg = reinterpret_cast<const T*>(p.yfwd);
+            uint2 y_n = make_uint2(0u, 0u);
+            if constexpr (EPI) {
+                const int4 pf = ptab[(sub * 16 < npos ? sub * 16 : 0) + pix_l];
+                const bool ok = cvalid && pf.z < lim_h && pf.w < lim_w;
+                y_n = *reinterpret_cast<const uint2*>(yimg + (ok ? out0 + (unsigned)pf.y : 0u));
+            }
             for (int g0 = sub * 16; g0 < npos; g0 += 16 * WPG) {
                 const int4 pe = ptab[g0 + pix_l];
+                const uint2 y_c = y_n;
+                if constexpr (EPI) {
+                    const int gn = g0 + 16 * WPG < npos ? g0 + 16 * WPG : g0;
+                    const int4 pf = ptab[gn + pix_l];
+                    const bool ok = cvalid && pf.z < lim_h && pf.w < lim_w;
+                    y_n = *reinterpret_cast<const uint2*>(yimg + (ok ? out0 + (unsigned)pf.y : 0u));
+                }
                 const T* bp = reinterpret_cast<const T*>(reinterpret_cast<const char*>(tile) + pe.x) + cl;
                 dw_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 // one tap row of B operands ahead of the MFMAs that consume it, so the LDS latency is paid once per
@@ -516,7 +544,13 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(DwParams p) {
                 if (cvalid && pe.z < lim_h && pe.w < lim_w) {
                     const unsigned idx = out0 + (unsigned)pe.y;
                     const f22 v = {v2f{acc[0], acc[1]}, v2f{acc[2], acc[3]}};
-                    dw_epilogue_store<T>(p, idx, v, es, eh, em, er, st_s, st_q);
+                    if constexpr (EPI) {
+                        dw_epilogue_store_pre<T>(p, idx, v, Raw4T<T>::unpack22(y_c), es, eh, em, er, st_s, st_q);
+                    } else {
+                        st_s.lo += v.lo; st_s.hi += v.hi;
+                        st_q.lo += v.lo * v.lo; st_q.hi += v.hi * v.hi;
+                        store22<T>(reinterpret_cast<T*>(p.y) + idx, v);
+                    }
                 }
             }
         }
@@ -1365,8 +1399,13 @@ static int launch_mfma(DwParams& p, int K, int S, float* stats, int part_rows, h
     dim3 grid((unsigned)(p.gx * p.ncb));
 #define MIA_DWM(K_, S_) \
     do { \
-        if (p.CB == 64) MIA_LAUNCH((dwconv_mfma_kernel<K_, S_, 64>), grid, dim3(256), lds, s, p); \
-        else MIA_LAUNCH((dwconv_mfma_kernel<K_, S_, 32>), grid, dim3(256), lds, s, p); \
+        if (p.yfwd) { \
+            if (p.CB == 64) MIA_LAUNCH((dwconv_mfma_kernel<K_, S_, 64, true>), grid, dim3(256), lds, s, p); \
+            else MIA_LAUNCH((dwconv_mfma_kernel<K_, S_, 32, true>), grid, dim3(256), lds, s, p); \
+        } else { \
+            if (p.CB == 64) MIA_LAUNCH((dwconv_mfma_kernel<K_, S_, 64, false>), grid, dim3(256), lds, s, p); \
+            else MIA_LAUNCH((dwconv_mfma_kernel<K_, S_, 32, false>), grid, dim3(256), lds, s, p); \
+        } \
     } while (0)
     if (K == 3 && S == 1) MIA_DWM(3, 1);
     else if (K == 3 && S == 2) MIA_DWM(3, 2);
@@ -1580,6 +1619,7 @@ extern "C" int mia_dwconv_bwd_data_lin(int dtype, const void* dy, int B, int H, 
                   "mia_dwconv_bwd_data_lin: null operand");
     MIA_CHECK_ARG(part_rows > 0 && part_rows <= 65535, "mia_dwconv_bwd_data_lin: bad part_rows");
     MIA_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dxp % 16) == 0, "mia_dwconv_bwd_data_lin: x and dxp must be 16-byte aligned");
+    MIA_CHECK_ARG(((uintptr_t)dy % 8) == 0 && ((uintptr_t)yfwd % 8) == 0, "mia_dwconv_bwd_data_lin: dy and yfwd must be 8-byte aligned");
     const int pad = (K - 1) / 2;
     DwParams p = {};
     p.x = dy; p.w = w; p.B = B; p.H = H; p.W = W; p.C = C;
