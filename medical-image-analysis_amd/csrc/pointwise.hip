@@ -764,6 +764,7 @@ __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* pool_part
 // ---- wide layers (C*RD large): the two FCs as batched register-tiled products, so that a weight row fetched
 // from L2 serves 8 images and every CU has work (one workgroup per image re-reads both matrices per image).
 constexpr int SE_JT = 4, SE_IB = 8;
+constexpr int SE_RT = 256;   // threads of the reduction kernel (512 measured slower: 8.6 -> 11.6 us at 2304 channels)
 
 // v[b][c] = inv_hw * sum_k part[b][k][c]                         (mode 0, forward pooling)
 // v[b][c] = (sum_k part[b][k][c]) * g[b][c] * (1 - g[b][c])      (mode 1, backward through the sigmoid)
@@ -781,19 +782,19 @@ __global__ __launch_bounds__(256) void se_prep_kernel(const float* part, int spl
     }
 }
 
-// d[b][j] = sum_c Wm[j][c] * v[b][c]; one wave per (4 rows j) x (8 images), lanes stride over c.
+// d[b][j] = sum_c Wm[j][c] * v[b][c]; one workgroup per (4 rows j) x (8 images): its waves split c, lanes stride
+// over it, and the partial sums meet in LDS in wave order.
 // mode 0: pre = d + bias[j] -> out[b][j]                     (forward hidden pre-activation)
 // mode 1: out[b][j] = d * silu'(hpre[b][j])                  (backward through the hidden SiLU)
 // vscale: v is used as v*vscale (the forward takes the per-image channel SUMS and folds the 1/HW of the mean in here);
 // vout (nullable): the waves of the first row tile also write v*vscale there (the pooled means the backward needs).
-__global__ __launch_bounds__(256) void se_reduce_c_kernel(const float* __restrict__ Wm, const float* __restrict__ v,
+__global__ __launch_bounds__(SE_RT) void se_reduce_c_kernel(const float* __restrict__ Wm, const float* __restrict__ v,
                                                           int B, int C, int RD, const float* bias, const float* hpre,
                                                           int mode, float* out, float vscale, float* vout) {
+    __shared__ float red[SE_RT / 64][SE_JT * SE_IB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int njt = (RD + SE_JT - 1) / SE_JT;
-    const int wid = blockIdx.x * 4 + wave;
-    const int jt = wid % njt, bt = wid / njt;
-    if (bt * SE_IB >= B) return;
+    const int jt = blockIdx.x % njt, bt = blockIdx.x / njt;
     const int j0 = jt * SE_JT, b0 = bt * SE_IB;
     const float* wp[SE_JT];
     const float* vp[SE_IB];
@@ -807,11 +808,12 @@ __global__ __launch_bounds__(256) void se_reduce_c_kernel(const float* __restric
 #pragma unroll
         for (int e = 0; e < SE_IB; ++e) acc[a][e] = 0.f;
     // This kernel sits on every block's critical chain with a handful of waves per CU: its duration is the number of
-    // dependent memory round trips, so the loop moves 16 bytes per lane and load and keeps two rounds in flight
-    // (4-byte loads, two rounds at a time: 14 us at 2304 channels, of which 12 were waiting).
+    // dependent memory round trips, so the loop moves 16 bytes per lane and load, keeps two rounds in flight
+    // (4-byte loads, two rounds at a time: 14 us at 2304 channels, of which 12 were waiting) and is split over the
+    // workgroup's waves.
     if ((C & 3) == 0) {
 #pragma unroll 2
-        for (int c = lane * 4; c < C; c += 256) {
+        for (int c = threadIdx.x * 4; c < C; c += SE_RT * 4) {
             float4 w[SE_JT], x[SE_IB];
 #pragma unroll
             for (int a = 0; a < SE_JT; ++a) w[a] = *reinterpret_cast<const float4*>(wp[a] + c);
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(256) void se_reduce_c_kernel(const float* __restric
         }
     } else {
 #pragma unroll 2
-        for (int c = lane; c < C; c += 64) {
+        for (int c = threadIdx.x; c < C; c += SE_RT) {
             float w[SE_JT], x[SE_IB];
 #pragma unroll
             for (int a = 0; a < SE_JT; ++a) w[a] = wp[a][c];
@@ -854,10 +856,16 @@ __global__ __launch_bounds__(256) void se_reduce_c_kernel(const float* __restric
     for (int a = 0; a < SE_JT; ++a)
 #pragma unroll
         for (int e = 0; e < SE_IB; ++e) {
-            const float t = wave_sum(acc[a][e]) * vscale;
+            const float t = wave_sum(acc[a][e]);
             if (lane == a * SE_IB + e) mine = t;
         }
-    if (lane < SE_JT * SE_IB) {
+    if (lane < SE_JT * SE_IB) red[wave][lane] = mine;
+    __syncthreads();
+    if (wave == 0 && lane < SE_JT * SE_IB) {
+        mine = 0.f;
+#pragma unroll
+        for (int w = 0; w < SE_RT / 64; ++w) mine += red[w][lane];
+        mine *= vscale;
         const int j = j0 + lane / SE_IB, b = b0 + lane % SE_IB;
         if (j < RD && b < B) {
             const size_t o = (size_t)b * RD + j;
@@ -914,12 +922,12 @@ extern "C" int mia_se_gate_fwd(const float* pool_part, int B, int splits, int HW
         if (splits == 1) {
             // one partial row per image: the "sum of the splits" is the row itself, and the 1/HW of the mean rides in
             // the first FC (which is linear in its input) -- one launch less on the block's critical chain
-            MIA_LAUNCH(se_reduce_c_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, s, Wr, pool_part, B, C, RD, br,
+            MIA_LAUNCH(se_reduce_c_kernel, dim3(waves), dim3(SE_RT), 0, s, Wr, pool_part, B, C, RD, br,
                        (const float*)nullptr, 0, hpre, 1.0f / (float)HW, pooled);
         } else {
             MIA_LAUNCH(se_prep_kernel, dim3(cdiv((long long)B * C, 256)), dim3(256), 0, s, pool_part, splits,
                        1.0f / (float)HW, C, B * C, (const float*)nullptr, 0, pooled);
-            MIA_LAUNCH(se_reduce_c_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, s, Wr, pooled, B, C, RD, br,
+            MIA_LAUNCH(se_reduce_c_kernel, dim3(waves), dim3(SE_RT), 0, s, Wr, pooled, B, C, RD, br,
                        (const float*)nullptr, 0, hpre, 1.f, (float*)nullptr);
         }
         MIA_LAUNCH(se_expand_kernel, dim3(cdiv(C, 256), cdiv(B, SE_IB)), dim3(256), (size_t)RD * SE_IB * 4, s,
@@ -1024,7 +1032,7 @@ extern "C" int mia_se_gate_bwd(const float* dgate_part, int B, int splits, int H
             MIA_LAUNCH(se_prep_kernel, dim3(cdiv((long long)B * C, 256)), dim3(256), 0, s, dgate_part, splits, 0.f,
                        C, B * C, gate, 1, dpre2);
         const int waves = cdiv(RD, SE_JT) * cdiv(B, SE_IB);
-        MIA_LAUNCH(se_reduce_c_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, s, WeT, dpre2, B, C, RD,
+        MIA_LAUNCH(se_reduce_c_kernel, dim3(waves), dim3(SE_RT), 0, s, WeT, dpre2, B, C, RD,
                            (const float*)nullptr, hpre, 1, dpre1, 1.f, (float*)nullptr);
         MIA_LAUNCH(se_expand_kernel, dim3(cdiv(C, 256), cdiv(B, SE_IB)), dim3(256), (size_t)RD * SE_IB * 4, s,
                            Wr, dpre1, B, C, RD, (const float*)nullptr, 1.0f / (float)HW, 1, dpool);
