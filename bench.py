@@ -84,6 +84,8 @@ def main():
                          "the expansion convolution")
     ap.add_argument("--linbn-min", type=int, default=0, help="A/B: smallest rows x expanded channels for that path")
     ap.add_argument("--no-fork", action="store_true", help="A/B switch: weight gradients on the main stream instead of the side stream")
+    ap.add_argument("--fork-min", type=int, default=0,
+                    help="A/B: smallest block (rows x expanded channels) whose weight gradients go to the side stream")
     ap.add_argument("--kernel-table", action="store_true", help="also print a per-family timing table to stderr")
     ap.add_argument("--nchw-input", action="store_true",
                     help="A/B switch: feed float32 NCHW images (the reference loaders' form) instead of the "
@@ -119,6 +121,8 @@ def main():
         ops.Side.enabled = False
     if args.no_linbn:
         ops.LinBN.enabled = False
+    if args.fork_min:
+        ops.Side.MIN_WORK = args.fork_min
     if args.linbn_min:
         ops.LinBN.MIN_ELEMS = args.linbn_min
 
