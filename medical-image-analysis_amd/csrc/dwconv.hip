@@ -130,27 +130,33 @@ __device__ __forceinline__ void dw_tile_fetch(TileRegs<T, NV>& t, const T* __res
                                               int c0px, int H, int W, int C, int cg, bool chan_ok, int pt, int npt) {
     t.inb = 0u;
     if (pt >= npt) return;
-    // The walk below depends only on (pt, tile shape), not on the tile's position; hiding pt from the optimiser
-    // makes it redo these few adds per tile instead of keeping 3*NV hoisted index registers alive across the
+    // The walk below depends only on (pt, tile shape), not on the tile's position. Its start (one division) is left to
+    // the optimiser to hoist out of the caller's tile loop; everything derived from it is hidden behind an opaque copy,
+    // so that the few adds are redone per tile instead of 3*NV hoisted index registers staying alive across the
     // compute phase (which would halve the occupancy).
-    asm volatile("" : "+v"(pt));
+    int row = pt / cols, col = pt - row * cols;
+    asm volatile("" : "+v"(pt), "+v"(row), "+v"(col));
     const int npix = rows * cols;
-    int pix = pt;
-    int row = pt / cols, col = pt - row * cols;   // one division per tile, not per pixel
     const int drow = npt / cols, dcol = npt - drow * cols;
+    // position and element offset advance together: one add per step and one more where the column wraps, instead of
+    // two integer multiplications per loaded vector (quarter-rate instructions: they were a third of the staging)
+    int pix = pt, ih = r0 + row, iw = c0px + col;
+    const int iw_end = c0px + cols;
+    unsigned off = (unsigned)((ih * W + iw) * C + cg);
+    const unsigned step = (unsigned)((drow * W + dcol) * C), wrap = (unsigned)((W - cols) * C);
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-        const int ih = r0 + row, iw = c0px + col;
-        const bool ok = pix < npix && chan_ok && ih >= 0 && ih < H && iw >= 0 && iw < W;
+        const bool ok = pix < npix && chan_ok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
         t.v[u] = Raw4T<T>::zero();
         if (ok) {
-            t.v[u] = *reinterpret_cast<const typename Raw4T<T>::type*>(img + (unsigned)((ih * W + iw) * C + cg));
+            t.v[u] = *reinterpret_cast<const typename Raw4T<T>::type*>(img + off);
             t.inb |= 1u << u;
         }
         pix += npt;
-        row += drow;
-        col += dcol;
-        if (col >= cols) { col -= cols; ++row; }
+        ih += drow;
+        iw += dcol;
+        off += step;
+        if (iw >= iw_end) { iw -= cols; ++ih; off += wrap; }
     }
 }
 
@@ -1015,10 +1021,20 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_lin_s2_kernel(DwParams p, D
 }
 
 // weight gradient: dW[c][kh][kw] = sum_{b,oh,ow} dY[b,oh,ow,c] * pro(x)[b, oh*S+kh-PAD, ow*S+kw-PAD, c]
-// A thread owns ONE tap row kh of one 4-channel vector (K accumulators), so the register footprint stays small
-// for 5x5 kernels too; the K tap rows of a channel vector are K different threads reading the same staged tiles.
-template <typename T, int K, int S>
+// A thread owns KR tap rows of one 4-channel vector (KR*K accumulators). KR = 1 keeps the register footprint small for
+// the 5x5 kernels (the K tap rows of a channel vector are K different threads reading the same staged tiles); KR = K
+// for 3x3: the four gradient vectors of a patch are read and unpacked once for all nine taps instead of once per tap
+// row, and the patch walk's address arithmetic is paid once instead of three times (per 72 packed FMAs: 22 LDS reads
+// instead of 30, 88 unpack instructions instead of 120).
+// SW (stride 1 with a prologue): the operands change roles. dW[t] = sum_q dY(q) * a(q + t - PAD) is also
+// sum_p a(p) * dY(p - t + PAD): the activated tensor is staged as the CENTRE tile and the gradient as the window with
+// the halo, and the result lands on the mirrored tap. The BatchNorm+SiLU prologue, which is what the staging costs,
+// then runs on TH*TW pixels per tile instead of (TH+K-1)*(TW+K-1) (8x16 tile, 3x3: 128 instead of 180).
+template <typename T, int K, int S, int KR, bool SW>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, const void* dyv, float* slab) {
+    static_assert(KR == 1 || KR == K, "a thread owns one tap row or all of them");
+    static_assert(!SW || S == 1, "the operands can change roles at stride 1 only");
+    constexpr int KG = K / KR;   // thread groups along the tap rows
     constexpr int PAD = (K - 1) / 2;
     constexpr int NIN = (DW_PW - 1) * S + K;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1028,8 +1044,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, cons
     T* tile = reinterpret_cast<T*>(red + 256 * 4);        // [IHT][IWT][CB]
     T* dtile = tile + (size_t)IHT * IWT * CB;             // [TH][TW][CB]
 
-    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
-    const T* __restrict__ dy = reinterpret_cast<const T*>(dyv);
+    // x: the operand staged with the halo, dy: the centre tile (the roles of the caller's tensors, see SW)
+    const T* __restrict__ x = reinterpret_cast<const T*>(SW ? dyv : p.x);
+    const T* __restrict__ dy = reinterpret_cast<const T*>(SW ? p.x : dyv);
     const int tid = threadIdx.x;
     int slot, cblk;
     dw_decode_block(p, slot, cblk);
@@ -1044,13 +1061,15 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, cons
     f22 psc = one, psh = zero;
     if (has_pro && s_chan_ok) { psc = load22<float>(p.pscale + c0 + s_cv * 4); psh = load22<float>(p.pshift + c0 + s_cv * 4); }
     // compute map: (pixel-thread, tap row, channel vector)
-    const int nkc = K * nvec, npt = 256 / nkc;
-    const int cv = tid % nvec, kh = (tid / nvec) % K, pt = tid / nkc;
+    const int nkc = KG * nvec, npt = 256 / nkc;
+    const int cv = tid % nvec, kh0 = ((tid / nvec) % KG) * KR, pt = tid / nkc;
     const bool cvalid = (cv * 4 < cbv) && (pt < npt);
 
-    f22 acc[K];
+    f22 acc[KR][K];
 #pragma unroll
-    for (int t = 0; t < K; ++t) acc[t] = f22{v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+    for (int r = 0; r < KR; ++r)
+#pragma unroll
+        for (int t = 0; t < K; ++t) acc[r][t] = f22{v2f{0.f, 0.f}, v2f{0.f, 0.f}};
 
     const int tiles_per_img = p.tiles_h * p.tiles_w;
     const int total = p.B * tiles_per_img;
@@ -1075,8 +1094,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, cons
     for (int wi = walk.first; wi < walk.count; wi += walk.stride) {
         const int work = walk.base + wi;
         __syncthreads();
-        dw_tile_commit<T, DW_NVX>(xregs, tile, IHT * IWT, s_cv, s_pt, s_npt, CB, has_pro, psc, psh);
-        dw_tile_commit<T, DW_NVD>(dregs, dtile, TH * TW, s_cv, s_pt, s_npt, CB, false, one, zero);
+        dw_tile_commit<T, DW_NVX>(xregs, tile, IHT * IWT, s_cv, s_pt, s_npt, CB, SW ? false : has_pro, psc, psh);
+        dw_tile_commit<T, DW_NVD>(dregs, dtile, TH * TW, s_cv, s_pt, s_npt, CB, SW ? has_pro : false, psc, psh);
         __syncthreads();
         if (wi + walk.stride < walk.count) fetch(work + walk.stride);  // in flight while this tile is reduced
         if (cvalid) {
@@ -1084,38 +1103,45 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwParams p, cons
             for (int patch = pt; patch < npatch; patch += npt) {
                 const int owl = pw * DW_PW;
                 const T* grow = dtile + (unsigned)((ph * TW + owl) * CB + cv * 4);
-                const T* row = tile + (unsigned)(((ph * S + kh) * IWT + owl * S) * CB + cv * 4);
-                f22 g[DW_PW], in[NIN];
+                const T* row = tile + (unsigned)(((ph * S + kh0) * IWT + owl * S) * CB + cv * 4);
+                f22 g[DW_PW];
 #pragma unroll
                 for (int q_ = 0; q_ < DW_PW; ++q_) g[q_] = load22<T>(grow + q_ * CB);
 #pragma unroll
-                for (int j = 0; j < NIN; ++j) in[j] = load22<T>(row + j * CB);
+                for (int r = 0; r < KR; ++r, row += IWT * CB) {
+                    f22 in[NIN];
 #pragma unroll
-                for (int kw = 0; kw < K; ++kw)
+                    for (int j = 0; j < NIN; ++j) in[j] = load22<T>(row + j * CB);
 #pragma unroll
-                    for (int q_ = 0; q_ < DW_PW; ++q_) fma22(acc[kw], in[q_ * S + kw], g[q_]);
+                    for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                        for (int q_ = 0; q_ < DW_PW; ++q_) fma22(acc[r][kw], in[q_ * S + kw], g[q_]);
+                }
                 ph += dph;
                 pw += dpw;
                 if (pw >= patches_w) { pw -= patches_w; ++ph; }
             }
         }
     }
-    // reduce over the pixel-threads of each (tap row, channel vector), one tap column at a time
+    // reduce over the pixel-threads of each (tap-row group, channel vector), one tap at a time
 #pragma unroll
-    for (int kw = 0; kw < K; ++kw) {
-        __syncthreads();
-        red[tid * 4 + 0] = acc[kw].lo.x; red[tid * 4 + 1] = acc[kw].lo.y;
-        red[tid * 4 + 2] = acc[kw].hi.x; red[tid * 4 + 3] = acc[kw].hi.y;
-        __syncthreads();
-        for (int t = tid; t < K * cbv; t += 256) {
-            const int khh = t / cbv, ch = t - khh * cbv;
-            const int v_ = ch >> 2, e = ch & 3;
-            float a = 0.f;
-            for (int q_ = 0; q_ < npt; ++q_) a += red[((q_ * K + khh) * nvec + v_) * 4 + e];
-            // slab row of this workgroup: [gridDim.x][C][K*K]; one plain store per output, no contention
-            slab[((size_t)slot * p.C + c0 + ch) * (K * K) + khh * K + kw] = a;
+    for (int r = 0; r < KR; ++r)
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+            __syncthreads();
+            red[tid * 4 + 0] = acc[r][kw].lo.x; red[tid * 4 + 1] = acc[r][kw].lo.y;
+            red[tid * 4 + 2] = acc[r][kw].hi.x; red[tid * 4 + 3] = acc[r][kw].hi.y;
+            __syncthreads();
+            for (int t = tid; t < KG * cbv; t += 256) {
+                const int kg = t / cbv, ch = t - kg * cbv;
+                const int v_ = ch >> 2, e = ch & 3;
+                float a = 0.f;
+                for (int q_ = 0; q_ < npt; ++q_) a += red[((q_ * KG + kg) * nvec + v_) * 4 + e];
+                // slab row of this workgroup: [gridDim.x][C][K*K]; one plain store per output, no contention
+                const int tap = (kg * KR + r) * K + kw;
+                slab[((size_t)slot * p.C + c0 + ch) * (K * K) + (SW ? K * K - 1 - tap : tap)] = a;
+            }
         }
-    }
 }
 
 // bf16 weight gradient on the matrix cores. With channels on both matrix axes and output pixels on the reduction
@@ -1722,8 +1748,22 @@ extern "C" int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int
     const size_t lds = 256 * 4 * 4 + ((size_t)IHT * IWT + (size_t)p.TH * p.TW) * p.CB * elem;
     p.gx = (int)gx; p.ncb = ncb;
     dim3 grid((unsigned)(gx * ncb));
-#define MIA_DWW(T_, K_, S_, PH_) \
-    MIA_LAUNCH((dwconv_bwd_weight_kernel<T_, K_, S_>), grid, dim3(256), lds, s, p, dy, ws)
+    // all tap rows per thread: measured ahead on the large 3x3 stride-1 maps only (75x75x192 268 -> 246 us; stride 2 and
+    // the 19x19 / 10x10 maps 3-20 % behind, where the 154 registers cost a wave per SIMD)
+    const bool rows3 = K == 3 && S == 1 && p.OH * p.OW > 1600;
+    const bool sw = S == 1 && pscale != nullptr;
+#define MIA_DWW_(T_, K_, S_, KR_, SW_) \
+    MIA_LAUNCH((dwconv_bwd_weight_kernel<T_, K_, S_, KR_, SW_>), grid, dim3(256), lds, s, p, dy, ws)
+#define MIA_DWW(T_, K_, S_, PH_)                                                              \
+    do {                                                                                      \
+        if (S_ == 1 && sw) {                                                                  \
+            if (K_ == 3 && rows3) MIA_DWW_(T_, K_, 1, (K_ == 3 ? 3 : 1), true);               \
+            else MIA_DWW_(T_, K_, 1, 1, true);                                                \
+        } else {                                                                              \
+            if (K_ == 3 && rows3) MIA_DWW_(T_, K_, S_, (K_ == 3 ? 3 : 1), false);             \
+            else MIA_DWW_(T_, K_, S_, 1, false);                                              \
+        }                                                                                     \
+    } while (0)
     if (dtype == MIA_BF16) {
         if (K == 3 && S == 1) MIA_DWW(bf16_t, 3, 1, 2);
         else if (K == 3 && S == 2) MIA_DWW(bf16_t, 3, 2, 1);
@@ -1736,6 +1776,7 @@ extern "C" int mia_dwconv_bwd_weight(int dtype, const void* x, int B, int H, int
         else MIA_DWW(float, 5, 2, 1);
     }
 #undef MIA_DWW
+#undef MIA_DWW_
     const long long nout = (long long)C * K * K;
     MIA_LAUNCH(slab_reduce_kernel, dim3(cdiv(nout, 32)), dim3(256), 0, s, ws, (int)gx, nout, dw);
     MIA_CHECK_LAUNCH("mia_dwconv_bwd_weight");
