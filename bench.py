@@ -101,13 +101,26 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     ndev = torch.cuda.device_count()
-    if world > ndev:
+    # MIA_BENCH_REHEARSAL=1: the ranks share the GPUs there are and talk over gloo (RCCL refuses two ranks on one
+    # device). It exists to run the N > 1 code path of this file on a one-GPU box; its numbers mean nothing and the
+    # line says so ("rehearsal": true).
+    rehearsal = world > 1 and os.environ.get("MIA_BENCH_REHEARSAL") == "1"
+    if world > ndev and not rehearsal:
         raise SystemExit(f"{world} ranks need {world} GPUs (one process per GPU over RCCL), this node has {ndev}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % max(ndev, 1))
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def reduce_scalar(t, op):
+        """all-reduce of a one-element tensor; on host memory under gloo (ddp.GradReducer stages its buckets likewise)"""
+        h = t.cpu() if rehearsal else t
+        dist.all_reduce(h, op=op)
+        return h
 
     import mia_amd
     from mia_amd import ops
@@ -231,18 +244,14 @@ def main():
     solo = ops.KernelTimer.stop()
     ops.Side.enabled = side_was
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(reduce_scalar(torch.tensor([dt], dtype=torch.float64, device=dev), dist.ReduceOp.MAX).item())
     loss_v = float(loss.item())
     first_loss_v = float(first_loss.item())
     in_sync = None
     if world > 1:
         # replicas started identical and applied identical averaged gradients: their parameters must still agree
         cs = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
-        lo, hi = cs.clone(), cs.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        lo, hi = reduce_scalar(cs.clone(), dist.ReduceOp.MIN), reduce_scalar(cs.clone(), dist.ReduceOp.MAX)
         in_sync = bool((lo == hi).item())
 
     if rank == 0:
@@ -295,6 +304,8 @@ def main():
                                    "region with that stream off (each kernel alone on the chip)")
         if in_sync is not None:
             out["replicas_in_sync"] = in_sync
+        if rehearsal:
+            out["rehearsal"] = True
         if args.kernel_table:
             tot = sum(v[1] for v in table.values())
             for fam, (n, fms, fb, _) in sorted(table.items(), key=lambda kv: -kv[1][1]):

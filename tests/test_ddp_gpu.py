@@ -168,3 +168,27 @@ def test_two_ranks_real_model_replicas_stay_in_sync():
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
     assert out.count("REHEARSAL OK") == 2 and out.count("replicas in sync: True") == 2, out[-3000:]
+
+
+def test_bench_two_rank_path_prints_the_contract_line():
+    """bench.py's N > 1 branch (rendezvous, barrier + MAX over ranks, exchange inside the step, replica check), run as
+    the driver launches it but with MIA_BENCH_REHEARSAL=1: two ranks share GPU 0 over gloo. The numbers mean nothing;
+    the line's fields and the replicas' agreement are what is checked."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps",
+           "3", "--warmup", "2", "--batch", "8"]
+    env = dict(os.environ, MIA_BENCH_REHEARSAL="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=170, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]        # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    assert d["replicas_in_sync"] is True and d["rehearsal"] is True
+    assert d["value"] > 0 and abs(d["value"] - 16 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
+    assert "cpu_baseline" not in d and d["vs_baseline"] is None
