@@ -233,7 +233,10 @@ constexpr int DW_NVD = 8;   //                          output-gradient tile
 // EPI: p.yfwd != nullptr (the data gradient's fused epilogue). A compile-time choice: the forward instance then carries
 // neither the epilogue's four channel vectors nor its branch (158 -> 142 registers at 3x3 stride 1, 142 -> 126 = four
 // waves per SIMD at stride 2; forward launches 3-11 % faster). Forcing the stride-1 instance down to 128 spills.
-template <typename T, int K, int S, int PH, bool EPI>
+// NV: staging slots per thread (12 or 16). Every slot costs its address walk and bounds tests whether or not the tile
+// reaches it; the tiles of the large maps fill 10-12 of 16 (180 pixels over 16 pixel-threads at 75x75x192, 264 over 25
+// at 150x150x40), so the host picks the 12-slot instance when the tile fits it.
+template <typename T, int K, int S, int PH, bool EPI, int NV>
 __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
     constexpr int PAD = (K - 1) / 2;
     constexpr int NIN = (DW_PW - 1) * S + K;   // staged input pixels per patch row
@@ -281,13 +284,13 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
     const int npatch = patches_h * patches_w;
     const int dph = npt / patches_w, dpw = npt - dph * patches_w;
 
-    TileRegs<T, DW_NV> regs;
+    TileRegs<T, NV> regs;
     auto fetch = [&](int work) {
         const int b = work / tiles_per_img;
         const int tr = work - b * tiles_per_img;
         const int trh = tr / p.tiles_w;
         const int oh0 = trh * TH, ow0 = (tr - trh * p.tiles_w) * TW;
-        dw_tile_fetch<T, DW_NV>(regs, x + (size_t)b * p.H * p.W * p.C, IHT, IWT, oh0 * S - PAD, ow0 * S - PAD, p.H, p.W,
+        dw_tile_fetch<T, NV>(regs, x + (size_t)b * p.H * p.W * p.C, IHT, IWT, oh0 * S - PAD, ow0 * S - PAD, p.H, p.W,
                                 p.C, c, chan_ok, pt, npt);
     };
     const TileWalk walk = make_tile_walk(total, slot, p.gx);
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DwParams p) {
         const int trh = tr / p.tiles_w;
         const int oh0 = trh * TH, ow0 = (tr - trh * p.tiles_w) * TW;
         __syncthreads();  // previous tile fully consumed
-        dw_tile_commit<T, DW_NV>(regs, tile, IHT * IWT, cv, pt, npt, CB, has_pro, psc, psh);
+        dw_tile_commit<T, NV>(regs, tile, IHT * IWT, cv, pt, npt, CB, has_pro, psc, psh);
         __syncthreads();
         if (wi + walk.stride < walk.count) fetch(work + walk.stride);  // in flight while this tile is computed
         if (cvalid) {
@@ -1333,8 +1336,14 @@ static void launch_tile(const DwParams& p, int grid_x, hipStream_t s) {
     DwParams q = p;
     q.gx = grid_x; q.ncb = cdiv(p.C, p.CB);
     dim3 grid((unsigned)(q.gx * q.ncb));
-    if (p.yfwd) MIA_LAUNCH((dwconv_tile_kernel<T, K, S, PH, true>), grid, dim3(256), lds, s, q);
-    else MIA_LAUNCH((dwconv_tile_kernel<T, K, S, PH, false>), grid, dim3(256), lds, s, q);
+    const bool few = cdiv(IHT * IWT, 256 / (p.CB / 4)) <= 12;   // staged pixels per pixel-thread
+    if (p.yfwd) {
+        if (few) MIA_LAUNCH((dwconv_tile_kernel<T, K, S, PH, true, 12>), grid, dim3(256), lds, s, q);
+        else MIA_LAUNCH((dwconv_tile_kernel<T, K, S, PH, true, DW_NV>), grid, dim3(256), lds, s, q);
+    } else {
+        if (few) MIA_LAUNCH((dwconv_tile_kernel<T, K, S, PH, false, 12>), grid, dim3(256), lds, s, q);
+        else MIA_LAUNCH((dwconv_tile_kernel<T, K, S, PH, false, DW_NV>), grid, dim3(256), lds, s, q);
+    }
 }
 
 template <typename T>
