@@ -185,6 +185,21 @@ for mode in ("fwd", "bwd"):
     CASES[f"se{mode}_s3"] = (lambda m=mode: se_case(576, 24, 361, m))
     CASES[f"se{mode}_s2"] = (lambda m=mode: se_case(288, 12, 1444, m))
 
+def sesums_case(H, C):
+    y, dz = rnd(B, H, H, C), rnd(B, H, H, C)
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    st = ops.bn_finalize_fwd(torch.randn(64, 2, C, device="cuda").abs(), 1000.0, ops.BNState(bn))
+    gate = torch.rand(B, C, device="cuda")
+    nbytes = (y.numel() + dz.numel()) * 2
+    return (lambda: ops.se_bwd_sums(y, dz, st, gate=gate)), nbytes
+
+CASES["sesums_s1"] = lambda: sesums_case(75, 192)
+CASES["sesums_s0"] = lambda: sesums_case(150, 40)
+CASES["sesums_s2"] = lambda: sesums_case(38, 288)
+CASES["sesums_s4"] = lambda: sesums_case(19, 816)
+CASES["sesums_s5"] = lambda: sesums_case(10, 1392)
+
+
 def bnfin_case(C, P, mode):
     part = torch.randn(P, 2, C, device="cuda").abs()
     bn = torch.nn.BatchNorm2d(C).cuda().train()
